@@ -1,0 +1,226 @@
+"""ctypes binding of oracle/_build/liborc.so (CPU restatement) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Arrays are numpy uint64, Montgomery limbs, exactly as the product's C ABI takes them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liborc.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "halo_cpu.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB_PATH
+
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class PP(C.Structure):
+    _fields_ = [("S", C.c_uint64 * 12), ("H", C.c_uint64 * 12), ("GS", u64p), ("N", C.c_size_t)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_last_error.restype = C.c_char_p
+        _lib.orc_rng_u64.restype = C.c_uint64
+    return _lib
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def proof_words(lg):
+    return 2 + 24 * lg + 32
+
+
+def instance_words(lg):
+    return 21 + proof_words(lg)
+
+
+def acc_words(lg):
+    return instance_words(lg) + 24
+
+
+def last_error() -> str:
+    return lib().orc_last_error().decode()
+
+
+def z(n):
+    return np.zeros(n, dtype=np.uint64)
+
+
+# ---- thin functional wrappers -------------------------------------------------
+def fr_to_mont(x: int):
+    a = np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    o = z(4); lib().orc_fr_to_mont(ptr(a), ptr(o)); return o
+
+
+def fr_from_mont(a) -> int:
+    o = z(4); lib().orc_fr_from_mont(ptr(np.ascontiguousarray(a, dtype=np.uint64)), ptr(o))
+    return sum(int(o[i]) << (64 * i) for i in range(4))
+
+
+def fq_from_mont(a) -> int:
+    o = z(4); lib().orc_fq_from_mont(ptr(np.ascontiguousarray(a, dtype=np.uint64)), ptr(o))
+    return sum(int(o[i]) << (64 * i) for i in range(4))
+
+
+def scalars_to_mont(xs):
+    out = np.zeros((len(xs), 4), dtype=np.uint64)
+    for i, x in enumerate(xs):
+        out[i] = fr_to_mont(int(x))
+    return out
+
+
+def point_canonical(jac):
+    """-> None for infinity, else (x, y) canonical ints."""
+    out = (C.c_uint8 * 64)()
+    inf = lib().orc_point_canonical(ptr(np.ascontiguousarray(jac, dtype=np.uint64)), out)
+    if inf:
+        return None
+    b = bytes(out)
+    return int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little")
+
+
+def affine_canonical(aff):
+    j = z(12); lib().orc_affine_to_jac(ptr(np.ascontiguousarray(aff, dtype=np.uint64)), ptr(j))
+    return point_canonical(j)
+
+
+def urs_affine(first: int, count: int):
+    out = np.zeros((count, 8), dtype=np.uint64)
+    lib().orc_urs_affine(C.c_uint64(first), C.c_size_t(count), ptr(out))
+    return out
+
+
+def rng_scalars(seed: int, n: int):
+    st = C.c_uint64(seed)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_rng_scalars(C.byref(st), C.c_size_t(n), ptr(out))
+    return out, st.value
+
+
+def make_pp(gs):
+    pp = PP()
+    lib().orc_pp_init(C.byref(pp), ptr(gs), C.c_size_t(gs.shape[0]))
+    pp._keep = gs
+    return pp
+
+
+def msm_affine(bases, scalars):
+    o = z(12); lib().orc_msm_affine(ptr(bases), ptr(scalars), C.c_size_t(min(len(bases), len(scalars))), ptr(o)); return o
+
+
+def msm_naive(bases, scalars):
+    o = z(12); lib().orc_msm_naive(ptr(bases), ptr(scalars), C.c_size_t(min(len(bases), len(scalars))), ptr(o)); return o
+
+
+def msm_jac(pts, scalars):
+    o = z(12); lib().orc_msm_jac(ptr(pts), ptr(scalars), C.c_size_t(min(len(pts), len(scalars))), ptr(o)); return o
+
+
+def scalar_dot(xs, ys):
+    o = z(4); lib().orc_scalar_dot(ptr(xs), ptr(ys), C.c_size_t(min(len(xs), len(ys))), ptr(o)); return o
+
+
+def powers(zm, n):
+    o = np.zeros((n, 4), dtype=np.uint64); lib().orc_powers(ptr(zm), C.c_size_t(n), ptr(o)); return o
+
+
+def h_coeffs(xis):
+    lg = len(xis) - 1
+    o = np.zeros((1 << lg, 4), dtype=np.uint64); lib().orc_h_coeffs(ptr(xis), C.c_size_t(lg), ptr(o)); return o
+
+
+def h_eval(xis, zm):
+    o = z(4); lib().orc_h_eval(ptr(xis), C.c_size_t(len(xis) - 1), ptr(zm), ptr(o)); return o
+
+
+def poly_eval(coeffs, zm):
+    o = z(4); lib().orc_poly_eval(ptr(coeffs), C.c_size_t(len(coeffs)), ptr(zm), ptr(o)); return o
+
+
+def pcdl_commit(pp, coeffs, d, w=None):
+    o = z(12)
+    rc = lib().orc_pcdl_commit(C.byref(pp), ptr(coeffs), C.c_size_t(len(coeffs)), C.c_size_t(d), ptr(w), ptr(o))
+    if rc:
+        raise AssertionError(last_error())
+    return o
+
+
+def pcdl_open(pp, seed, coeffs, Cj, d, zm, w=None):
+    lg = (d + 1).bit_length() - 1
+    st = C.c_uint64(seed)
+    pf = z(proof_words(lg))
+    rc = lib().orc_pcdl_open(C.byref(pp), C.byref(st), ptr(coeffs), C.c_size_t(len(coeffs)), ptr(Cj), C.c_size_t(d),
+                             ptr(zm), ptr(w), ptr(pf))
+    if rc:
+        raise AssertionError(last_error())
+    return pf, st.value
+
+
+def pcdl_succinct_check(pp, Cj, d, zm, vm, pf):
+    lg = (d + 1).bit_length() - 1
+    xis = np.zeros((lg + 1, 4), dtype=np.uint64); U = z(12)
+    rc = lib().orc_pcdl_succinct_check(C.byref(pp), ptr(Cj), C.c_size_t(d), ptr(zm), ptr(vm), ptr(pf), ptr(xis), ptr(U))
+    if rc:
+        raise ValueError(last_error())
+    return xis, U
+
+
+def pcdl_check(pp, Cj, d, zm, vm, pf):
+    rc = lib().orc_pcdl_check(C.byref(pp), ptr(Cj), C.c_size_t(d), ptr(zm), ptr(vm), ptr(pf))
+    if rc:
+        raise ValueError(last_error())
+
+
+def random_instance(pp, seed, d):
+    lg = (d + 1).bit_length() - 1
+    st = C.c_uint64(seed); inst = z(instance_words(lg))
+    rc = lib().orc_random_instance(C.byref(pp), C.byref(st), C.c_size_t(d), ptr(inst))
+    if rc:
+        raise AssertionError(last_error())
+    return inst, st.value
+
+
+def acc_prover(pp, seed, d, instances):
+    lg = (d + 1).bit_length() - 1
+    qs = np.ascontiguousarray(np.concatenate(instances)) if len(instances) else z(0)
+    st = C.c_uint64(seed); acc = z(acc_words(lg))
+    rc = lib().orc_acc_prover(C.byref(pp), C.byref(st), C.c_size_t(d), ptr(qs), C.c_size_t(len(instances)), ptr(acc))
+    if rc:
+        raise ValueError(last_error())
+    return acc, st.value
+
+
+def acc_verifier(pp, d, instances, acc):
+    qs = np.ascontiguousarray(np.concatenate(instances)) if len(instances) else z(0)
+    rc = lib().orc_acc_verifier(C.byref(pp), C.c_size_t(d), ptr(qs), C.c_size_t(len(instances)), ptr(acc))
+    if rc:
+        raise ValueError(last_error())
+
+
+def acc_decider(pp, acc):
+    rc = lib().orc_acc_decider(C.byref(pp), ptr(acc))
+    if rc:
+        raise ValueError(last_error())
