@@ -1,0 +1,290 @@
+"""ctypes binding of libhalo_hip.so (include/halo_accumulation.h) and its build recipe."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_PATH = os.path.join(PKG, "libhalo_hip.so")
+
+HALO_OK, HALO_E_ASSERT, HALO_E_REJECT, HALO_E_ARG, HALO_E_DEVICE = 0, -1, -2, -3, -4
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class HaloError(RuntimeError):
+    """Raised for HALO_E_ARG / HALO_E_DEVICE (library-level failures)."""
+
+
+class HaloReject(ValueError):
+    """The reference's `ensure!` -> Err (verifier-side rejection)."""
+
+
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compile every HIP translation unit for gfx950 into libhalo_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".hpp", ".cpp"))]
+    srcs.append(os.path.join(PKG, "..", "include", "halo_accumulation.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j", str(jobs), "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGS = {
+    "halo_last_error": (C.c_char_p, []),
+    "halo_device_count": (C.c_int, []),
+    "halo_ctx_create": (C.c_int, [C.c_int, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_create_urs": (C.c_int, [C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_destroy": (None, [C.c_void_p]),
+    "halo_ctx_size": (C.c_size_t, [C.c_void_p]),
+    "halo_ctx_read_bases": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p]),
+    "halo_ctx_bases_dev": (C.c_void_p, [C.c_void_p]),
+    "halo_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "halo_public_points": (C.c_int, [u64p, u64p]),
+    "halo_msm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_int, u64p]),
+    "halo_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, u64p]),
+    "halo_msm_points": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    "halo_scalar_dot": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    "halo_powers": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "halo_poly_eval": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p]),
+    "halo_h_coeffs": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "halo_h_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "halo_h_eval_batch": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
+    "halo_h_accumulate": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, u64p]),
+    "halo_ipa_begin": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, C.POINTER(C.c_void_p)]),
+    "halo_ipa_round_lr": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "halo_ipa_round_fold": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "halo_ipa_finish": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "halo_ipa_destroy": (None, [C.c_void_p]),
+    "halo_ipa_len": (C.c_size_t, [C.c_void_p]),
+    "halo_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_prof_reset": (C.c_int, [C.c_void_p]),
+    "halo_prof_count": (C.c_int, [C.c_void_p]),
+    "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
+    "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen libhalo_hip.so; fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HaloError("libhalo_hip.so is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need contiguous uint64 array"
+    return a.ctypes.data_as(u64p)
+
+
+def check(rc: int) -> None:
+    if rc == HALO_OK:
+        return
+    msg = load().halo_last_error().decode()
+    if rc == HALO_E_ASSERT:
+        raise AssertionError(msg)
+    if rc == HALO_E_REJECT:
+        raise HaloReject(msg)
+    raise HaloError("%s (code %d)" % (msg, rc))
+
+
+class Context:
+    """A commitment key resident on one GPU (consts.rs: N, GS)."""
+
+    def __init__(self, bases=None, *, urs_n: int | None = None, first_index: int = 2, device: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        if bases is not None:
+            bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+            check(lib.halo_ctx_create(device, ptr(bases), bases.shape[0], C.byref(h)))
+        else:
+            check(lib.halo_ctx_create_urs(device, first_index, int(urs_n), C.byref(h)))
+        self.h = h
+        self.lib = lib
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.halo_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self) -> int:
+        return self.lib.halo_ctx_size(self.h)
+
+    def read_bases(self, off=0, n=None):
+        n = self.size - off if n is None else n
+        out = np.zeros((n, 8), dtype=np.uint64)
+        check(self.lib.halo_ctx_read_bases(self.h, off, n, ptr(out)))
+        return out
+
+    # ---- group.rs
+    def msm(self, scalars, off=0, mont=True):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm(self.h, off, scalars.shape[0], ptr(scalars), int(mont), ptr(out)))
+        return out
+
+    def msm_dev(self, dptr: int, n: int, off=0, mont=True):
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm_dev(self.h, off, n, C.c_void_p(dptr), int(mont), ptr(out)))
+        return out
+
+    def msm_points(self, pts_jac, scalars):
+        pts_jac = np.ascontiguousarray(pts_jac, dtype=np.uint64).reshape(-1, 12)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        m = min(len(pts_jac), len(scalars))  # msm_unchecked zips to the shorter input
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm_points(self.h, ptr(pts_jac), ptr(scalars), m, ptr(out)))
+        return out
+
+    def scalar_dot(self, xs, ys):
+        xs = np.ascontiguousarray(xs, dtype=np.uint64).reshape(-1, 4)
+        ys = np.ascontiguousarray(ys, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.lib.halo_scalar_dot(self.h, ptr(xs), ptr(ys), min(len(xs), len(ys)), ptr(out)))
+        return out
+
+    def powers(self, z, n):
+        out = np.zeros((n, 4), dtype=np.uint64)
+        check(self.lib.halo_powers(self.h, ptr(np.ascontiguousarray(z, dtype=np.uint64)), n, ptr(out)))
+        return out
+
+    def poly_eval(self, coeffs, z):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.lib.halo_poly_eval(self.h, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)), ptr(out)))
+        return out
+
+    # ---- h(X)
+    def h_coeffs(self, xis):
+        xis = np.ascontiguousarray(xis, dtype=np.uint64).reshape(-1, 4)
+        lg = xis.shape[0] - 1
+        out = np.zeros((1 << lg, 4), dtype=np.uint64)
+        check(self.lib.halo_h_coeffs(self.h, ptr(xis), lg, ptr(out)))
+        return out
+
+    def h_commit(self, xis):
+        xis = np.ascontiguousarray(xis, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_h_commit(self.h, ptr(xis), xis.shape[0] - 1, ptr(out)))
+        return out
+
+    def h_eval_batch(self, xis, z):
+        xis = np.ascontiguousarray(xis, dtype=np.uint64)
+        m, lg1 = xis.shape[0], xis.shape[1]
+        out = np.zeros((m, 4), dtype=np.uint64)
+        check(self.lib.halo_h_eval_batch(self.h, ptr(xis), m, lg1 - 1, ptr(np.ascontiguousarray(z, dtype=np.uint64)), ptr(out)))
+        return out
+
+    def h_accumulate(self, h0, xis, alphas):
+        xis = np.ascontiguousarray(xis, dtype=np.uint64)
+        m, lg1 = xis.shape[0], xis.shape[1]
+        out = np.zeros((1 << (lg1 - 1), 4), dtype=np.uint64)
+        h0 = None if h0 is None else np.ascontiguousarray(h0, dtype=np.uint64)
+        check(self.lib.halo_h_accumulate(self.h, ptr(h0), ptr(xis), ptr(np.ascontiguousarray(alphas, dtype=np.uint64)), m, lg1 - 1, ptr(out)))
+        return out
+
+    # ---- measurement
+    def prof_enable(self, on=True):
+        check(self.lib.halo_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        check(self.lib.halo_prof_reset(self.h))
+
+    def prof(self):
+        out = {}
+        for i in range(self.lib.halo_prof_count(self.h)):
+            name, ms, cnt = C.c_char_p(), C.c_double(), C.c_long()
+            check(self.lib.halo_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    def set_window_bits(self, c):
+        check(self.lib.halo_set_window_bits(self.h, c))
+
+    # ---- primitive hooks
+    def field_op(self, field, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros_like(a)
+        check(self.lib.halo_test_field_op(self.h, field, op, ptr(a), ptr(b), a.shape[0], ptr(out)))
+        return out
+
+    def point_op(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(a)
+        check(self.lib.halo_test_point_op(self.h, op, ptr(a), ptr(b), a.shape[0], ptr(out)))
+        return out
+
+
+class Ipa:
+    """Device-resident state of pcdl::open's halving loop (pcdl.rs:183-231)."""
+
+    def __init__(self, ctx: Context, n: int, coeffs, z):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        h = C.c_void_p()
+        check(ctx.lib.halo_ipa_begin(ctx.h, n, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)), C.byref(h)))
+        self.h, self.ctx = h, ctx
+
+    def round_lr(self, H_prime):
+        L, R = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_round_lr(self.h, ptr(np.ascontiguousarray(H_prime, dtype=np.uint64)), ptr(L), ptr(R)))
+        return L, R
+
+    def round_fold(self, xi, xi_inv):
+        check(self.ctx.lib.halo_ipa_round_fold(self.h, ptr(np.ascontiguousarray(xi, dtype=np.uint64)), ptr(np.ascontiguousarray(xi_inv, dtype=np.uint64))))
+
+    def finish(self):
+        U, c = np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_finish(self.h, ptr(U), ptr(c)))
+        return U, c
+
+    def __len__(self):
+        return self.ctx.lib.halo_ipa_len(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.halo_ipa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def public_points():
+    S, H = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    check(load().halo_public_points(ptr(S), ptr(H)))
+    return S, H

@@ -1,0 +1,388 @@
+// Host-side Pallas arithmetic for the glue the reference keeps on the CPU between kernels:
+// Fiat-Shamir hashing (group.rs:41-89), challenge inversion (pcdl.rs:213), the O(lg n)
+// succinct check (pcdl.rs:252-314), the final window combine of an MSM and the
+// normalisation of points that leave the library.  4 x 64-bit limb Montgomery (R = 2^256),
+// the same in-memory form arkworks uses, so limbs cross the C ABI untouched.
+//
+// This is product code (linked into libhalo_hip.so); it shares nothing with oracle/.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace halo {
+namespace host {
+
+using u64 = uint64_t;
+using u128 = unsigned __int128;
+
+struct FqP {
+    static constexpr u64 M[4] = {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0ULL, 0x4000000000000000ULL};
+    static constexpr u64 ONE[4] = {0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+    static constexpr u64 R2[4] = {0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL};
+    static constexpr u64 INV = 0x992d30ecffffffffULL;
+};
+struct FrP {
+    static constexpr u64 M[4] = {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0ULL, 0x4000000000000000ULL};
+    static constexpr u64 ONE[4] = {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+    static constexpr u64 R2[4] = {0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL};
+    static constexpr u64 INV = 0x8c46eb20ffffffffULL;
+};
+
+template <class P>
+struct Fp {
+    u64 l[4];
+
+    static Fp zero() { return Fp{{0, 0, 0, 0}}; }
+    static Fp one() { return Fp{{P::ONE[0], P::ONE[1], P::ONE[2], P::ONE[3]}}; }
+    static Fp load(const u64 *p) { Fp r; std::memcpy(r.l, p, 32); return r; }
+    void store(u64 *p) const { std::memcpy(p, l, 32); }
+    bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+    bool operator==(const Fp &o) const { return std::memcmp(l, o.l, 32) == 0; }
+    bool operator!=(const Fp &o) const { return !(*this == o); }
+
+    static bool geq(const u64 a[4], const u64 b[4]) {
+        for (int i = 3; i >= 0; --i)
+            if (a[i] != b[i]) return a[i] > b[i];
+        return true;
+    }
+    static u64 sub_limbs(u64 r[4], const u64 a[4], const u64 b[4]) {
+        u64 borrow = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 d = (u128)a[i] - b[i] - borrow;
+            r[i] = (u64)d;
+            borrow = (u64)(d >> 64) & 1;
+        }
+        return borrow;
+    }
+    static u64 add_limbs(u64 r[4], const u64 a[4], const u64 b[4]) {
+        u64 carry = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 s = (u128)a[i] + b[i] + carry;
+            r[i] = (u64)s;
+            carry = (u64)(s >> 64);
+        }
+        return carry;
+    }
+    Fp operator+(const Fp &o) const {
+        Fp r;
+        add_limbs(r.l, l, o.l);  // < 2M < 2^256
+        if (geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
+        return r;
+    }
+    Fp operator-(const Fp &o) const {
+        Fp r;
+        if (sub_limbs(r.l, l, o.l)) add_limbs(r.l, r.l, P::M);
+        return r;
+    }
+    Fp operator-() const {
+        if (is_zero()) return *this;
+        Fp r;
+        sub_limbs(r.l, P::M, l);
+        return r;
+    }
+    // Montgomery product, product scanning with a 192-bit column accumulator
+    Fp operator*(const Fp &o) const {
+        u64 t[8];
+        u128 acc = 0;
+        u64 hi = 0;
+        for (int k = 0; k < 8; ++k) {
+            int lo_i = k < 4 ? 0 : k - 3, hi_i = k < 4 ? k : 3;
+            for (int i = lo_i; i <= hi_i; ++i) {
+                u128 p = (u128)l[i] * o.l[k - i];
+                acc += p;
+                if (acc < p) ++hi;
+            }
+            t[k] = (u64)acc;
+            acc = (acc >> 64) | ((u128)hi << 64);
+            hi = 0;
+            if (k == 7) break;
+        }
+        // word-wise Montgomery reduction of t[0..8)
+        u64 extra = 0;
+        for (int i = 0; i < 4; ++i) {
+            u64 m = t[i] * P::INV;
+            u128 c = 0;
+            for (int j = 0; j < 4; ++j) {
+                c += (u128)m * P::M[j] + t[i + j];
+                t[i + j] = (u64)c;
+                c >>= 64;
+            }
+            for (int j = i + 4; j < 8 && c; ++j) {
+                c += t[j];
+                t[j] = (u64)c;
+                c >>= 64;
+            }
+            extra += (u64)c;
+        }
+        Fp r{{t[4], t[5], t[6], t[7]}};
+        if (extra || geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
+        return r;
+    }
+    Fp sqr() const { return *this * *this; }
+    Fp dbl() const { return *this + *this; }
+    Fp from_mont() const { return *this * Fp{{1, 0, 0, 0}}; }
+    Fp to_mont() const { return *this * Fp{{P::R2[0], P::R2[1], P::R2[2], P::R2[3]}}; }
+    static Fp from_u64(u64 v) { return Fp{{v, 0, 0, 0}}.to_mont(); }
+    // reduce a 256-bit little-endian integer mod M (ark-ff from_le_bytes_mod_order on 32 bytes)
+    static Fp from_le_bytes_mod_order(const uint8_t b[32]) {
+        Fp v;
+        std::memcpy(v.l, b, 32);
+        while (geq(v.l, P::M)) sub_limbs(v.l, v.l, P::M);  // 2^256 < 4M
+        return v.to_mont();
+    }
+    Fp pow(const u64 e[4]) const {
+        Fp acc = one();
+        for (int i = 255; i >= 0; --i) {
+            acc = acc.sqr();
+            if ((e[i / 64] >> (i % 64)) & 1) acc = acc * *this;
+        }
+        return acc;
+    }
+    // Fermat inverse; caller checks for zero (ark-ff inverse() -> None)
+    Fp inv() const {
+        u64 e[4], two[4] = {2, 0, 0, 0};
+        sub_limbs(e, P::M, two);
+        return pow(e);
+    }
+};
+
+using Fq = Fp<FqP>;
+using Fr = Fp<FrP>;
+
+// ------------------------------------------------------------------ points
+struct Affine {
+    Fq x, y;
+    bool inf;
+};
+struct Point {  // Jacobian, Z = 0 infinity
+    Fq X, Y, Z;
+
+    static Point infinity() { return Point{Fq::one(), Fq::one(), Fq::zero()}; }
+    static Point from_affine(const Fq &x, const Fq &y) { return Point{x, y, Fq::one()}; }
+    static Point load(const u64 *w) { return Point{Fq::load(w), Fq::load(w + 4), Fq::load(w + 8)}; }
+    static Point load_affine(const u64 *w) {
+        Fq x = Fq::load(w), y = Fq::load(w + 4);
+        if (x.is_zero() && y.is_zero()) return infinity();
+        return from_affine(x, y);
+    }
+    static Point generator() { return from_affine(-Fq::one(), Fq::one().dbl()); }  // (-1, 2)
+    bool is_inf() const { return Z.is_zero(); }
+
+    Point dbl() const {  // dbl-2009-l
+        if (is_inf()) return *this;
+        Fq A = X.sqr(), B = Y.sqr(), C = B.sqr();
+        Fq D = ((X + B).sqr() - A - C).dbl();
+        Fq E = A.dbl() + A, F = E.sqr();
+        Point r;
+        r.X = F - D.dbl();
+        r.Y = E * (D - r.X) - C.dbl().dbl().dbl();
+        r.Z = (Y * Z).dbl();
+        return r;
+    }
+    Point operator+(const Point &q) const {  // add-2007-bl
+        if (is_inf()) return q;
+        if (q.is_inf()) return *this;
+        Fq Z1Z1 = Z.sqr(), Z2Z2 = q.Z.sqr();
+        Fq U1 = X * Z2Z2, U2 = q.X * Z1Z1;
+        Fq S1 = Y * q.Z * Z2Z2, S2 = q.Y * Z * Z1Z1;
+        if (U1 == U2) return S1 == S2 ? dbl() : infinity();
+        Fq H = U2 - U1, I = H.dbl().sqr(), J = H * I, rr = (S2 - S1).dbl(), V = U1 * I;
+        Point r;
+        r.X = rr.sqr() - J - V.dbl();
+        r.Y = rr * (V - r.X) - (S1 * J).dbl();
+        r.Z = ((Z + q.Z).sqr() - Z1Z1 - Z2Z2) * H;
+        return r;
+    }
+    Point operator-() const { return Point{X, -Y, Z}; }
+    Point operator-(const Point &q) const { return *this + (-q); }
+    bool operator==(const Point &q) const {  // projective equality, as ark-ec
+        if (is_inf() || q.is_inf()) return is_inf() && q.is_inf();
+        Fq Z1Z1 = Z.sqr(), Z2Z2 = q.Z.sqr();
+        if (X * Z2Z2 != q.X * Z1Z1) return false;
+        return Y * Z2Z2 * q.Z == q.Y * Z1Z1 * Z;
+    }
+    bool operator!=(const Point &q) const { return !(*this == q); }
+    // scalar multiple by a Montgomery-form Fr, 4-bit fixed windows
+    Point mul(const Fr &k_mont) const {
+        Fr k = k_mont.from_mont();
+        Point tbl[16];
+        tbl[0] = infinity();
+        tbl[1] = *this;
+        for (int i = 2; i < 16; ++i) tbl[i] = (i & 1) ? tbl[i - 1] + *this : tbl[i / 2].dbl();
+        Point acc = infinity();
+        for (int w = 63; w >= 0; --w) {
+            if (!acc.is_inf()) acc = acc.dbl().dbl().dbl().dbl();
+            unsigned nib = (unsigned)(k.l[w / 16] >> (4 * (w % 16))) & 15u;
+            if (nib) acc = acc + tbl[nib];
+        }
+        return acc;
+    }
+    Affine to_affine() const {
+        if (is_inf()) return Affine{Fq::zero(), Fq::zero(), true};
+        Fq zi = Z.inv(), zi2 = zi.sqr();
+        return Affine{X * zi2, Y * zi2 * zi, false};
+    }
+    Point normalized() const {
+        if (is_inf()) return infinity();
+        Affine a = to_affine();
+        return from_affine(a.x, a.y);
+    }
+    void store(u64 *w) const { X.store(w); Y.store(w + 4); Z.store(w + 8); }
+    void store_normalized(u64 *w) const { normalized().store(w); }
+};
+
+// sum_i k_i * P_i for a handful of points (succinct check, acc.rs:178): interleaved 4-bit windows
+inline Point small_msm(const std::vector<Point> &pts, const std::vector<Fr> &ks_mont) {
+    size_t n = pts.size() < ks_mont.size() ? pts.size() : ks_mont.size();
+    std::vector<std::array<Point, 16>> tbl(n);
+    std::vector<Fr> ks(n);
+    for (size_t i = 0; i < n; ++i) {
+        ks[i] = ks_mont[i].from_mont();
+        tbl[i][0] = Point::infinity();
+        tbl[i][1] = pts[i];
+        for (int j = 2; j < 16; ++j) tbl[i][j] = (j & 1) ? tbl[i][j - 1] + pts[i] : tbl[i][j / 2].dbl();
+    }
+    Point acc = Point::infinity();
+    for (int w = 63; w >= 0; --w) {
+        if (!acc.is_inf()) acc = acc.dbl().dbl().dbl().dbl();
+        for (size_t i = 0; i < n; ++i) {
+            unsigned nib = (unsigned)(ks[i].l[w / 16] >> (4 * (w % 16))) & 15u;
+            if (nib) acc = acc + tbl[i][nib];
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------ SHA3-256 (FIPS 202)
+class Sha3_256 {
+   public:
+    Sha3_256() { std::memset(st_, 0, sizeof st_); }
+    void update(const void *data, size_t len) {
+        const uint8_t *p = static_cast<const uint8_t *>(data);
+        while (len--) {
+            reinterpret_cast<uint8_t *>(st_)[pos_++] ^= *p++;
+            if (pos_ == kRate) { permute(); pos_ = 0; }
+        }
+    }
+    void finalize(uint8_t out[32]) {
+        uint8_t *b = reinterpret_cast<uint8_t *>(st_);
+        b[pos_] ^= 0x06;
+        b[kRate - 1] ^= 0x80;
+        permute();
+        std::memcpy(out, st_, 32);
+    }
+
+   private:
+    static constexpr size_t kRate = 136;
+    u64 st_[25];
+    size_t pos_ = 0;
+    static u64 rol(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+    void permute() {
+        static const u64 RC[24] = {
+            0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+            0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+            0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+            0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+            0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+            0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        u64 *a = st_;
+        for (int r = 0; r < 24; ++r) {
+            u64 c[5], d[5];
+            for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+            for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+            for (int i = 0; i < 25; ++i) a[i] ^= d[i % 5];
+            // rho + pi
+            u64 b[25];
+            int x = 1, y = 0;
+            b[0] = a[0];
+            u64 cur = a[1];
+            for (int t = 0; t < 24; ++t) {
+                int rot = ((t + 1) * (t + 2) / 2) % 64;
+                int nx = y, ny = (2 * x + 3 * y) % 5;
+                b[nx + 5 * ny] = rot ? rol(cur, rot) : cur;
+                x = nx; y = ny;
+                cur = a[x + 5 * y];
+            }
+            for (int yy = 0; yy < 25; yy += 5)
+                for (int xx = 0; xx < 5; ++xx) a[yy + xx] = b[yy + xx] ^ (~b[yy + (xx + 1) % 5] & b[yy + (xx + 2) % 5]);
+            a[0] ^= RC[r];
+        }
+    }
+};
+
+// ------------------------------------------------------------------ transcript (group.rs:41-89)
+// ark-serialize 0.5 compressed encodings.  UNVERIFIED against the reference (no Rust
+// toolchain, no known-answer vector in the reference): "parity unpinned", see DESIGN.md.
+class Transcript {
+   public:
+    void scalar(const Fr &s_mont) {
+        Fr c = s_mont.from_mont();
+        put(c.l, 32);
+    }
+    void point(const Point &p) {
+        uint8_t out[33] = {0};
+        if (p.is_inf()) {
+            out[32] = 0x40;
+        } else {
+            Affine a = p.to_affine();
+            Fq x = a.x.from_mont(), y = a.y.from_mont(), ny = (-a.y).from_mont();
+            std::memcpy(out, x.l, 32);
+            bool y_gt = !Fq::geq(ny.l, y.l);  // y > -y  => "negative" flag
+            if (y_gt) out[32] |= 0x80;
+        }
+        put(out, 33);
+    }
+    void u64le(u64 v) { put(&v, 8); }
+    void byte(uint8_t v) { put(&v, 1); }
+    Fr finish(uint32_t tag) {  // tag 0 = rho_0!, 1 = rho_1!
+        Sha3_256 h;
+        h.update(buf_.data(), buf_.size());
+        h.update(&tag, 4);
+        uint8_t dig[32];
+        h.finalize(dig);
+        buf_.clear();
+        return Fr::from_le_bytes_mod_order(dig);
+    }
+
+   private:
+    std::vector<uint8_t> buf_;
+    void put(const void *p, size_t n) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        buf_.insert(buf_.end(), b, b + n);
+    }
+};
+
+// main.rs:18-32: scalar of generator `index`
+inline Fr urs_scalar(u64 index) {
+    static const char kGenesis[] = "To understand recursion, one must first understand recursion";
+    Sha3_256 h;
+    h.update(kGenesis, sizeof(kGenesis) - 1);
+    h.update(&index, 8);
+    uint8_t dig[32];
+    h.finalize(dig);
+    return Fr::from_le_bytes_mod_order(dig);
+}
+
+// SplitMix64 stream shared with the tests' input generator
+struct Rng {
+    u64 state;
+    u64 next() {
+        state += 0x9E3779B97F4A7C15ULL;
+        u64 z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    Fr scalar() {
+        Fr v;
+        for (int i = 0; i < 4; ++i) v.l[i] = next();
+        while (Fr::geq(v.l, FrP::M)) Fr::sub_limbs(v.l, v.l, FrP::M);
+        return v.to_mont();
+    }
+};
+
+}  // namespace host
+}  // namespace halo

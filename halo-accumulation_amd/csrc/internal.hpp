@@ -1,0 +1,119 @@
+// Internal declarations shared by the translation units of libhalo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/halo_accumulation.h"
+#include "host_math.hpp"
+
+namespace halo {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define HALO_HIP(expr)                                   \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+struct ProfEntry {
+    const char *name;
+    double total_ms = 0;
+    long launches = 0;
+};
+
+struct Profiler {
+    bool on = false;
+    std::vector<ProfEntry> entries;
+    struct Pending { int idx; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    int find(const char *name);
+    void begin(const char *name, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();  // needs the stream to be idle
+};
+
+// Launch wrapper: brackets the launch with events when profiling is on.
+#define HALO_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
+    do {                                                                                     \
+        if ((ctx)->prof.on) (ctx)->prof.begin(name, (ctx)->stream);                          \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);          \
+        if ((ctx)->prof.on) (ctx)->prof.end((ctx)->stream);                                  \
+    } while (0)
+
+struct MsmPlan {
+    int c;        // window bits
+    int W;        // windows = ceil(256 / c)
+    uint32_t B;   // buckets per window = 2^(c-1)
+};
+MsmPlan msm_plan(size_t n, int forced_c);
+
+struct MsmWorkspace {
+    size_t cap_n = 0;
+    uint64_t *d_canon = nullptr;     // n x 4 canonical scalars
+    uint32_t *d_counts = nullptr;    // W*B
+    uint32_t *d_starts = nullptr;    // W*B exclusive scan within 4096-entry blocks
+    uint32_t *d_blockoff = nullptr;  // per 4096-entry block offset
+    uint32_t *d_cursor = nullptr;    // W*B
+    uint32_t *d_sorted = nullptr;    // n*W entries: point index | sign << 31
+    uint64_t *d_buckets = nullptr;   // W*B x 16 (XYZZ)
+    uint64_t *d_seg = nullptr;       // W*64 x 2 x 16 (S, T per 512-bucket segment)
+    uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
+    uint64_t *h_winsum = nullptr;    // pinned
+    size_t cap_counts = 0, cap_sorted = 0;
+};
+
+}  // namespace halo
+
+struct halo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t n = 0;
+    uint64_t *d_bases = nullptr;  // n x 8 affine
+    halo::MsmWorkspace ws;
+    halo::Profiler prof;
+    int window_bits = 0;
+    // scratch for host-pointer entry points
+    uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
+    size_t tmp_words = 0;
+    uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
+};
+
+struct halo_ipa {
+    halo_ctx *ctx = nullptr;
+    size_t n = 0, m = 0;  // m = current length (n, n/2, ...)
+    uint64_t *d_G = nullptr;  // m x 8 affine (in-place)
+    uint64_t *d_c = nullptr;  // m x 4
+    uint64_t *d_z = nullptr;  // m x 4
+};
+
+namespace halo {
+
+// ---- msm.hip
+int msm_workspace_alloc(halo_ctx *ctx, size_t n);
+void msm_workspace_free(halo_ctx *ctx);
+// sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
+int msm_run(halo_ctx *ctx, const uint64_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);
+int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out_affine);
+int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint64_t *d_out_affine);
+int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+
+// ---- ipa.hip
+int ipa_fold_points(halo_ctx *ctx, uint64_t *d_G, size_t m, const host::Fr &xi_mont);
+int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv);
+// out[0] = <xs0, ys0>, out[1] = <xs1, ys1> (either pair may be null to skip)
+int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
+            host::Fr out[2]);
+int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out);
+int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host::Fr &z, host::Fr *out);
+// d_out[k] (+)= scale * prod_{bit i of k} xis[lg_n - i]
+int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr &scale, bool accumulate, uint64_t *d_out);
+int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out);
+
+}  // namespace halo

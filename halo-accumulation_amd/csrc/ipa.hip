@@ -1,0 +1,299 @@
+// K3-K9: the kernels behind pcdl::open's halving loop (pcdl.rs:195-227), construct_powers
+// (group.rs:29-37), scalar_dot (group.rs:13-15), p(z) (pcdl.rs:135) and h(X) (pcdl.rs:56-91).
+//
+// Fr work is one 32-byte element per lane, loaded as two dwordx4 from contiguous arrays
+// (coalesced 2 KiB per wave-instruction pair); these kernels are the HBM-bound part of the path.
+// The point fold uses ONE scalar for the whole launch, so every lane runs the same
+// double-and-add schedule with no divergence.
+#include "curve.cuh"
+#include "internal.hpp"
+
+namespace halo {
+
+struct FeArg { uint32_t v[8]; };  // by-value kernel argument (SGPRs)
+static FeArg to_arg(const host::Fr &f) {
+    FeArg a;
+    for (int i = 0; i < 4; ++i) { a.v[2 * i] = (uint32_t)f.l[i]; a.v[2 * i + 1] = (uint32_t)(f.l[i] >> 32); }
+    return a;
+}
+HALO_DEV Fe from_arg(const FeArg &a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
+    return r;
+}
+
+// ------------------------------------------------------------------ K3: G'[j] = G[j] + xi * G[j+m]
+__global__ __launch_bounds__(256) void k_fold_points(uint64_t *__restrict__ G, uint32_t m, FeArg xi_canon) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    Aff hi = aff_load(G + 8 * (size_t)(j + m));
+    Aff lo = aff_load(G + 8 * (size_t)j);
+    Jac acc = jac_inf();
+#pragma unroll 1
+    for (int limb = 7; limb >= 0; limb--) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) word = (q == limb) ? xi_canon.v[q] : word;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = jac_dbl(acc);
+            if ((word >> bit) & 1u) acc = jac_madd(acc, hi);  // wave-uniform branch
+        }
+    }
+    acc = jac_madd(acc, lo);
+    aff_store(G + 8 * (size_t)j, jac_to_aff(acc));
+}
+
+// ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
+__global__ __launch_bounds__(256) void k_fold_scalars(uint64_t *__restrict__ c, uint64_t *__restrict__ z, uint32_t m, FeArg xi,
+                                                      FeArg xi_inv) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    Fe x = from_arg(xi), xinv = from_arg(xi_inv);
+    Fe cl = fe_load(c + 4 * (size_t)j), cr = fe_load(c + 4 * (size_t)(j + m));
+    Fe zl = fe_load(z + 4 * (size_t)j), zr = fe_load(z + 4 * (size_t)(j + m));
+    fe_store(c + 4 * (size_t)j, fe_add<FrCfg>(cl, fe_mul<FrCfg>(cr, xinv)));
+    fe_store(z + 4 * (size_t)j, fe_add<FrCfg>(zl, fe_mul<FrCfg>(zr, x)));
+}
+
+// ------------------------------------------------------------------ block-wide Fr sum
+HALO_DEV Fe block_sum_fr(Fe v, Fe *lds /* >= 4 entries */) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int off = 32; off >= 1; off >>= 1) {
+        Fe o = fe_shfl(v, (lane + off) & 63);
+        if (lane < off) v = fe_add<FrCfg>(v, o);
+    }
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) v = fe_add<FrCfg>(v, lds[w]);
+    }
+    return v;  // valid in thread 0
+}
+
+// ------------------------------------------------------------------ K5: two dot products per launch
+__global__ __launch_bounds__(256) void k_dot2_partial(const uint64_t *__restrict__ xs0, const uint64_t *__restrict__ ys0,
+                                                      const uint64_t *__restrict__ xs1, const uint64_t *__restrict__ ys1, uint32_t m,
+                                                      uint64_t *__restrict__ partial) {
+    __shared__ Fe lds[8];
+    Fe a0 = fe_zero(), a1 = fe_zero();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        if (xs0) a0 = fe_add<FrCfg>(a0, fe_mul<FrCfg>(fe_load(xs0 + 4 * (size_t)i), fe_load(ys0 + 4 * (size_t)i)));
+        if (xs1) a1 = fe_add<FrCfg>(a1, fe_mul<FrCfg>(fe_load(xs1 + 4 * (size_t)i), fe_load(ys1 + 4 * (size_t)i)));
+    }
+    Fe s0 = block_sum_fr(a0, lds);
+    __syncthreads();
+    Fe s1 = block_sum_fr(a1, lds + 4);
+    if (threadIdx.x == 0) {
+        fe_store(partial + 8 * (size_t)blockIdx.x, s0);
+        fe_store(partial + 8 * (size_t)blockIdx.x + 4, s1);
+    }
+}
+// sums `count` partial records of `width` Fr each into out[width]
+__global__ __launch_bounds__(256) void k_sum_partials(const uint64_t *__restrict__ partial, uint32_t count, uint32_t width,
+                                                      uint64_t *__restrict__ out) {
+    __shared__ Fe lds[4];
+    for (uint32_t k = 0; k < width; k++) {
+        Fe a = fe_zero();
+        for (uint32_t i = threadIdx.x; i < count; i += 256) a = fe_add<FrCfg>(a, fe_load(partial + 4 * ((size_t)i * width + k)));
+        Fe s = block_sum_fr(a, lds);
+        if (threadIdx.x == 0) fe_store(out + 4 * (size_t)k, s);
+        __syncthreads();
+    }
+}
+
+// z^e from the table pw[k] = z^(2^k), e < 2^nbits
+HALO_DEV Fe pow_from_table(const uint64_t *__restrict__ pw, uint32_t e, int nbits) {
+    Fe acc = fe_one<FrCfg>();
+#pragma unroll 1
+    for (int k = 0; k < nbits; k++) {
+        if ((e >> k) & 1u) acc = fe_mul<FrCfg>(acc, fe_load(pw + 4 * (size_t)k));
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------ K6: out[i] = z^i
+__global__ __launch_bounds__(256) void k_powers(const uint64_t *__restrict__ pw, int nbits, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t e0 = t * 8;
+    if (e0 >= n) return;
+    Fe z = fe_load(pw);
+    Fe cur = pow_from_table(pw, e0, nbits);
+#pragma unroll 1
+    for (int k = 0; k < 8 && e0 + k < n; k++) {
+        fe_store(out + 4 * (size_t)(e0 + k), cur);
+        cur = fe_mul<FrCfg>(cur, z);
+    }
+}
+
+// ------------------------------------------------------------------ K9: p(z), 16 coefficients per lane
+__global__ __launch_bounds__(256) void k_poly_eval_partial(const uint64_t *__restrict__ coeffs, uint32_t len,
+                                                           const uint64_t *__restrict__ pw, int nbits, uint64_t *__restrict__ partial) {
+    __shared__ Fe lds[4];
+    Fe z = fe_load(pw);
+    Fe acc = fe_zero();
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t * 16 < len; t += gridDim.x * 256) {
+        uint32_t base = t * 16;
+        Fe h = fe_zero();
+#pragma unroll 1
+        for (int k = 15; k >= 0; k--) {
+            h = fe_mul<FrCfg>(h, z);
+            if (base + k < len) h = fe_add<FrCfg>(h, fe_load(coeffs + 4 * (size_t)(base + k)));
+        }
+        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(h, pow_from_table(pw, base, nbits)));
+    }
+    Fe s = block_sum_fr(acc, lds);
+    if (threadIdx.x == 0) fe_store(partial + 4 * (size_t)blockIdx.x, s);
+}
+
+// ------------------------------------------------------------------ K7: h coefficients from three 256-entry tables
+__global__ __launch_bounds__(256) void k_h_coeffs(const uint64_t *__restrict__ tab /* low | mid | high, 256 x 4 each */, uint32_t n,
+                                                  int accumulate, uint64_t *__restrict__ out) {
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    Fe lo = fe_load(tab + 4 * (size_t)(k & 255u));
+    Fe mi = fe_load(tab + 4 * (size_t)(256 + ((k >> 8) & 255u)));
+    Fe hi = fe_load(tab + 4 * (size_t)(512 + ((k >> 16) & 255u)));
+    Fe v = fe_mul<FrCfg>(fe_mul<FrCfg>(lo, mi), hi);
+    if (accumulate) v = fe_add<FrCfg>(v, fe_load(out + 4 * (size_t)k));
+    fe_store(out + 4 * (size_t)k, v);
+}
+
+// ------------------------------------------------------------------ K8: HPoly::eval, one polynomial per lane
+__global__ __launch_bounds__(256) void k_h_eval(const uint64_t *__restrict__ xis, uint32_t m, int lg_n, FeArg zarg,
+                                                uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t *x = xis + 4 * (size_t)i * (size_t)(lg_n + 1);
+    Fe z = from_arg(zarg), one = fe_one<FrCfg>();
+    Fe v = fe_add<FrCfg>(one, fe_mul<FrCfg>(fe_load(x + 4 * (size_t)lg_n), z));
+    Fe zi = z;
+#pragma unroll 1
+    for (int k = 1; k < lg_n; k++) {
+        zi = fe_sqr<FrCfg>(zi);
+        v = fe_mul<FrCfg>(v, fe_add<FrCfg>(one, fe_mul<FrCfg>(fe_load(x + 4 * (size_t)(lg_n - k)), zi)));
+    }
+    fe_store(out + 4 * (size_t)i, v);
+}
+
+// ================================================================== host launchers
+int ipa_fold_points(halo_ctx *ctx, uint64_t *d_G, size_t m, const host::Fr &xi_mont) {
+    if (m == 0) return HALO_OK;
+    FeArg xi = to_arg(xi_mont.from_mont());
+    HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, xi);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv) {
+    if (m == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_fold_scalars", k_fold_scalars, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_c, d_z, (uint32_t)m, to_arg(xi),
+                to_arg(xi_inv));
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+static unsigned reduce_blocks(size_t work_items) {
+    size_t nb = (work_items + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb == 0) nb = 1;
+    return (unsigned)nb;
+}
+
+int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
+            host::Fr out[2]) {
+    out[0] = out[1] = host::Fr::zero();
+    if (m == 0) return HALO_OK;
+    unsigned nb = reduce_blocks(m);
+    uint64_t *partial = ctx->d_tmp_c;  // >= 1024 * 8 words
+    HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial, dim3(nb), dim3(256), 0, xs0, ys0, xs1, ys1, (uint32_t)m, partial);
+    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 2u, partial + 8 * 1024);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipMemcpyAsync(ctx->h_pinned, partial + 8 * 1024, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    out[0] = host::Fr::load(ctx->h_pinned);
+    out[1] = host::Fr::load(ctx->h_pinned + 4);
+    return HALO_OK;
+}
+
+// pw[k] = z^(2^k), k < 32, staged through the pinned page (slot at word 64)
+static int upload_pow_table(halo_ctx *ctx, const host::Fr &z, uint64_t *d_pw) {
+    host::Fr cur = z;
+    uint64_t *h = ctx->h_pinned + 64;
+    for (int k = 0; k < 32; ++k) { cur.store(h + 4 * k); cur = cur.sqr(); }
+    HALO_HIP(hipMemcpyAsync(d_pw, h, 32 * 32, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));  // the pinned page is reused by the next call
+    return HALO_OK;
+}
+static int bits_for(size_t n) {
+    int b = 0;
+    while (((size_t)1 << b) < n) b++;
+    return b < 1 ? 1 : b;
+}
+
+int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out) {
+    if (n == 0) return HALO_OK;
+    uint64_t *d_pw = ctx->d_tmp_c + 8 * 1024 + 64;
+    int rc = upload_pow_table(ctx, z, d_pw);
+    if (rc) return rc;
+    size_t threads = (n + 7) / 8;
+    HALO_LAUNCH(ctx, "k_powers", k_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, d_pw, bits_for(n), (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host::Fr &z, host::Fr *out) {
+    *out = host::Fr::zero();
+    if (len == 0) return HALO_OK;
+    uint64_t *d_pw = ctx->d_tmp_c + 8 * 1024 + 64;
+    int rc = upload_pow_table(ctx, z, d_pw);
+    if (rc) return rc;
+    unsigned nb = reduce_blocks((len + 15) / 16);
+    uint64_t *partial = ctx->d_tmp_c;
+    HALO_LAUNCH(ctx, "k_poly_eval_partial", k_poly_eval_partial, dim3(nb), dim3(256), 0, d_coeffs, (uint32_t)len, d_pw, bits_for(len),
+                partial);
+    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 1u, partial + 8 * 1024);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipMemcpyAsync(ctx->h_pinned, partial + 8 * 1024, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    *out = host::Fr::load(ctx->h_pinned);
+    return HALO_OK;
+}
+
+int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr &scale, bool accumulate, uint64_t *d_out) {
+    if (lg_n > 24) { set_error("h_coeffs: lg_n > 24 unsupported"); return HALO_E_ARG; }
+    // coefficient k = prod over set bits i of k of xis[lg_n - i]  (pcdl.rs:496-505)
+    std::vector<uint64_t> tab(3 * 256 * 4);
+    for (int level = 0; level < 3; ++level) {
+        std::vector<host::Fr> t(256, host::Fr::one());
+        if (level == 2) t[0] = scale;
+        size_t len = 1;
+        for (int b = 0; b < 8; ++b) {
+            size_t bit = (size_t)level * 8 + b;
+            if (bit >= lg_n) break;
+            const host::Fr &x = xis[lg_n - bit];
+            for (size_t k = 0; k < len; ++k) t[len + k] = t[k] * x;
+            len *= 2;
+        }
+        if (level == 2 && len == 1) t[0] = scale;
+        for (size_t k = 0; k < 256; ++k) t[k].store(&tab[((size_t)level * 256 + k) * 4]);
+    }
+    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 256;
+    HALO_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));  // `tab` is pageable and dies at return
+    size_t n = (size_t)1 << lg_n;
+    HALO_LAUNCH(ctx, "k_h_coeffs", k_h_coeffs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_tab, (uint32_t)n, accumulate ? 1 : 0,
+                d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out) {
+    if (m == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_h_eval", k_h_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_xis, (uint32_t)m, (int)lg_n, to_arg(z), d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+}  // namespace halo

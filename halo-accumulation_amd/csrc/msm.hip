@@ -1,0 +1,460 @@
+// K1/K2 Pippenger MSM on gfx950 (replaces ark-ec's msm_unchecked as called from
+// group.rs:18-26), K10 batch_to_affine, K11 URS generation (main.rs:18-45) and the primitive
+// test hooks.
+//
+// Pipeline for n points, window c bits, W = ceil(256/c) windows, B = 2^(c-1) buckets each
+// (signed digits, so a point with digit d lands in bucket |d|-1 of its window, negated if d<0):
+//   k_msm_count     : scalar out of Montgomery form (arkworks `into_bigint`), signed-digit
+//                     recode, histogram of bucket sizes          (reads 32 B/scalar, coalesced)
+//   k_scan_*        : exclusive scan of the W*B bucket sizes
+//   k_msm_scatter   : point indices grouped by bucket
+//   k_msm_accumulate: one lane per bucket, XYZZ mixed adds over its index list (gathers 64 B/pt)
+//   k_msm_reduce1/2 : sum_k k*B_k per window with lane-local running sums + wave64 shuffle
+//                     scans (no serial chain longer than ~35 group operations)
+//   host            : Horner over the W window sums (240 doublings are a 60 us job for one
+//                     CPU core and a ~1.5 ms serial chain for one GPU lane)
+#include "curve.cuh"
+#include "internal.hpp"
+
+namespace halo {
+
+// ------------------------------------------------------------------------------ plan
+MsmPlan msm_plan(size_t n, int forced_c) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = forced_c > 0 ? forced_c : lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    MsmPlan p;
+    p.c = c;
+    p.W = (256 + c - 1) / c;
+    p.B = 1u << (c - 1);
+    return p;
+}
+
+// ------------------------------------------------------------------------------ recode
+// Signed digit of window w: v = bits + carry; v > B  =>  v - 2^c (carry 1).  Top window never
+// carries out because c*W >= 256 > 255 bits.  Returns magnitude (0 = skip) and sign.
+struct Digit { uint32_t mag; uint32_t neg; };
+HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c, uint32_t B, uint32_t &carry) {
+    uint32_t bit = (uint32_t)w * (uint32_t)c;
+    uint32_t word = bit >> 5, sh = bit & 31;
+    uint64_t two = (uint64_t)words[word] | ((uint64_t)words[word + 1] << 32);
+    uint32_t raw = (uint32_t)(two >> sh) & ((1u << c) - 1u);
+    uint32_t v = raw + carry;
+    Digit d;
+    if (v > B) { d.mag = (1u << c) - v; d.neg = 1; carry = 1; }
+    else { d.mag = v; d.neg = 0; carry = 0; }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_msm_count(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int W,
+                                                   uint32_t B, uint64_t *__restrict__ canon, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t sw[256 * 9];
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe s = fe_load(scalars + 4 * (size_t)i);
+    if (mont) s = fe_from_mont<FrCfg>(s);
+    fe_store(canon + 4 * (size_t)i, s);
+    uint32_t *my = sw + threadIdx.x * 9;
+#pragma unroll
+    for (int k = 0; k < 8; k++) my[k] = s.v[k];
+    my[8] = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        Digit d = next_digit(my, w, c, B, carry);
+        if (d.mag) atomicAdd(&counts[(uint32_t)w * B + d.mag - 1], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_msm_scatter(const uint64_t *__restrict__ canon, uint32_t n, int c, int W, uint32_t B,
+                                                     const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
+                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t sw[256 * 9];
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe s = fe_load(canon + 4 * (size_t)i);
+    uint32_t *my = sw + threadIdx.x * 9;
+#pragma unroll
+    for (int k = 0; k < 8; k++) my[k] = s.v[k];
+    my[8] = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        Digit d = next_digit(my, w, c, B, carry);
+        if (d.mag) {
+            uint32_t g = (uint32_t)w * B + d.mag - 1;
+            uint32_t pos = atomicAdd(&cursor[g], 1u);
+            sorted[starts[g] + blockoff[g >> 12] + pos] = i | (d.neg << 31);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ scan
+// 4096 entries per block: local exclusive scan + block total.
+__global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t total, uint32_t *__restrict__ out,
+                                                     uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t part[256];
+    uint32_t base = blockIdx.x * 4096 + threadIdx.x * 16;
+    uint32_t loc[16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t v = (base + k < total) ? in[base + k] : 0u;
+        loc[k] = sum;
+        sum += v;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (uint32_t)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t excl = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (base + k < total) out[base + k] = excl + loc[k];
+    if (threadIdx.x == 255) blocksum[blockIdx.x] = part[255];
+}
+// exclusive scan of up to 1024 block totals, in place
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *blocksum, uint32_t nblocks) {
+    __shared__ uint32_t part[1024];
+    uint32_t v0 = threadIdx.x < nblocks ? blocksum[threadIdx.x] : 0u;
+    part[threadIdx.x] = v0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (uint32_t)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x < nblocks) blocksum[threadIdx.x] = part[threadIdx.x] - v0;
+}
+
+// ------------------------------------------------------------------------------ accumulate
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
+                                                        const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
+                                                        const uint32_t *__restrict__ counts, uint32_t total_buckets,
+                                                        uint64_t *__restrict__ buckets) {
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total_buckets) return;
+    uint32_t cnt = counts[g];
+    uint32_t st = starts[g] + blockoff[g >> 12];
+    Xyzz acc = xyzz_inf();
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t e = sorted[st + k];
+        Aff p = aff_load(bases + 8 * (size_t)(e & 0x7fffffffu));
+        p = aff_cneg(p, (e >> 31) != 0);
+        xyzz_madd(acc, p);
+    }
+    xyzz_store(buckets + 16 * (size_t)g, acc);
+}
+
+// ------------------------------------------------------------------------------ reduce
+// Lane l holds S (sum of its buckets) and T (their sum weighted 1..L relative to the lane's
+// first bucket).  Returns in lane 0: S_tot = sum_l S_l and T_tot = sum_l (T_l + l * 2^k * S_l).
+HALO_DEV void wave_weighted_sum(Xyzz &S, Xyzz &T, int k) {
+    int lane = threadIdx.x & 63;
+    // inclusive suffix scan: S_l <- sum_{j >= l} S_j
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        Xyzz o = xyzz_shfl(S, (lane + off) & 63);
+        if (lane + off < 64) xyzz_add(S, o);
+    }
+    // sum_{l>=1} suffix_l = sum_l l * S_l
+    Xyzz V = (lane >= 1) ? S : xyzz_inf();
+#pragma unroll 1
+    for (int i = 0; i < k; i++) V = xyzz_dbl(V);
+    xyzz_add(T, V);
+#pragma unroll 1
+    for (int off = 32; off >= 1; off >>= 1) {
+        Xyzz o = xyzz_shfl(T, (lane + off) & 63);
+        if (lane < off) xyzz_add(T, o);
+    }
+}
+
+// one wave per (window, segment of 64*L buckets)
+__global__ __launch_bounds__(64) void k_msm_reduce1(const uint64_t *__restrict__ buckets, uint32_t B, uint32_t L, int logL,
+                                                    uint32_t nseg, uint64_t *__restrict__ seg) {
+    uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
+    uint32_t lane = threadIdx.x;
+    uint32_t first = s * 64 * L + lane * L;
+    Xyzz run = xyzz_inf(), tot = xyzz_inf();
+#pragma unroll 1
+    for (int j = (int)L - 1; j >= 0; j--) {
+        uint32_t idx = first + (uint32_t)j;
+        Xyzz b = xyzz_inf();
+        if (idx < B) b = xyzz_load(buckets + 16 * ((size_t)w * B + idx));
+        xyzz_add(run, b);
+        xyzz_add(tot, run);
+    }
+    wave_weighted_sum(run, tot, logL);
+    if (lane == 0) {
+        uint64_t *o = seg + 32 * ((size_t)w * nseg + s);
+        xyzz_store(o, run);
+        xyzz_store(o + 16, tot);
+    }
+}
+// one wave per window over its nseg <= 64 segments; segment stride = 64*L buckets = 2^seg_shift
+__global__ __launch_bounds__(64) void k_msm_reduce2(const uint64_t *__restrict__ seg, uint32_t nseg, int seg_shift,
+                                                    uint64_t *__restrict__ winsum) {
+    uint32_t w = blockIdx.x, lane = threadIdx.x;
+    Xyzz S = xyzz_inf(), T = xyzz_inf();
+    if (lane < nseg) {
+        const uint64_t *o = seg + 32 * ((size_t)w * nseg + lane);
+        S = xyzz_load(o);
+        T = xyzz_load(o + 16);
+    }
+    wave_weighted_sum(S, T, seg_shift);
+    if (lane == 0) jac_store(winsum + 12 * (size_t)w, xyzz_to_jac(T));
+}
+
+// ------------------------------------------------------------------------------ K10 / K11
+__global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Jac p = jac_load(jac + 12 * (size_t)i);
+    aff_store(out + 8 * (size_t)i, jac_to_aff(p));
+}
+// table[w][d] = d * 16^w * (-1, 2), d in 0..15 (d = 0 stored as infinity): 64 mixed adds, no doublings
+__global__ __launch_bounds__(256) void k_urs(const uint64_t *__restrict__ table, const uint32_t *__restrict__ canon, uint32_t n,
+                                             uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Jac acc = jac_inf();
+#pragma unroll 1
+    for (int limb = 0; limb < 8; limb++) {
+        uint32_t word = canon[8 * (size_t)i + limb];
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            uint32_t nib = (word >> (4 * k)) & 15u;
+            Aff t = aff_load(table + 8 * (size_t)((limb * 8 + k) * 16 + nib));
+            acc = jac_madd(acc, t);
+        }
+    }
+    aff_store(out + 8 * (size_t)i, jac_to_aff(acc));
+}
+
+// ------------------------------------------------------------------------------ test hooks
+template <class F>
+__global__ __launch_bounds__(256) void k_test_field(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe x = fe_load(a + 4 * (size_t)i);
+    Fe y = b ? fe_load(b + 4 * (size_t)i) : fe_zero();
+    Fe r;
+    switch (op) {
+        case 0: r = fe_mul<F>(x, y); break;
+        case 1: r = fe_add<F>(x, y); break;
+        case 2: r = fe_sub<F>(x, y); break;
+        case 3: r = fe_is_zero(x) ? fe_zero() : fe_inv<F>(x); break;
+        case 4: r = fe_from_mont<F>(x); break;
+        default: r = fe_to_mont<F>(x); break;
+    }
+    fe_store(out + 4 * (size_t)i, r);
+}
+HALO_DEV Xyzz jac_to_xyzz(const Jac &p) {
+    if (jac_is_inf(p)) return xyzz_inf();
+    Xyzz r; r.x = p.x; r.y = p.y; r.zz = fe_sqr<Q>(p.z); r.zzz = fe_mul<Q>(r.zz, p.z); return r;
+}
+__global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Jac p = jac_load(a + 12 * (size_t)i);
+    Jac r;
+    if (op == 0) {
+        Xyzz x = jac_to_xyzz(p);
+        xyzz_add(x, jac_to_xyzz(jac_load(b + 12 * (size_t)i)));
+        r = xyzz_to_jac(x);
+    } else if (op == 1) {
+        Aff q = aff_load(b + 8 * (size_t)i);
+        Xyzz x = jac_to_xyzz(p);
+        xyzz_madd(x, q);
+        Jac r1 = xyzz_to_jac(x);
+        Jac r2 = jac_madd(p, q);  // both mixed-add forms must agree; disagreement poisons the output
+        Aff a1 = jac_to_aff(r1), a2 = jac_to_aff(r2);
+        r = (fe_eq(a1.x, a2.x) && fe_eq(a1.y, a2.y)) ? r2 : jac_from_aff(Aff{fe_one<Q>(), fe_one<Q>()});
+    } else if (op == 2) {
+        Jac r1 = jac_dbl(p);
+        Jac r2 = xyzz_to_jac(xyzz_dbl(jac_to_xyzz(p)));
+        Aff a1 = jac_to_aff(r1), a2 = jac_to_aff(r2);
+        r = (fe_eq(a1.x, a2.x) && fe_eq(a1.y, a2.y)) ? r1 : jac_from_aff(Aff{fe_one<Q>(), fe_one<Q>()});
+    } else {
+        // p * scalar (Montgomery Fr), MSB-first double-and-add on the affine form of p
+        Fe k = fe_from_mont<FrCfg>(fe_load(b + 4 * (size_t)i));
+        Aff pa = jac_to_aff(p);
+        Jac acc = jac_inf();
+#pragma unroll 1
+        for (int limb = 7; limb >= 0; limb--) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) word = (q == limb) ? k.v[q] : word;
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; bit--) {
+                acc = jac_dbl(acc);
+                if ((word >> bit) & 1u) acc = jac_madd(acc, pa);
+            }
+        }
+        r = acc;
+    }
+    jac_store(out + 12 * (size_t)i, r);
+}
+
+int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (field == 0) HALO_LAUNCH(ctx, "k_test_field", k_test_field<FqCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+    else HALO_LAUNCH(ctx, "k_test_field", k_test_field<FrCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    HALO_LAUNCH(ctx, "k_test_point", k_test_point, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint64_t *d_out) {
+    if (n == 0) return HALO_OK;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    HALO_LAUNCH(ctx, "k_batch_to_affine", k_batch_to_affine, grid, block, 0, d_jac, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+// ------------------------------------------------------------------------------ URS
+static const std::vector<uint64_t> &urs_table() {
+    static std::vector<uint64_t> tbl;
+    if (tbl.empty()) {
+        tbl.assign(64 * 16 * 8, 0);
+        host::Point base = host::Point::generator();
+        for (int w = 0; w < 64; ++w) {
+            host::Point acc = host::Point::infinity();
+            for (int d = 1; d < 16; ++d) {
+                acc = acc + base;
+                host::Affine a = acc.to_affine();
+                a.x.store(&tbl[(size_t)(w * 16 + d) * 8]);
+                a.y.store(&tbl[(size_t)(w * 16 + d) * 8 + 4]);
+            }
+            base = base.dbl().dbl().dbl().dbl();
+        }
+    }
+    return tbl;
+}
+
+int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out) {
+    if (n == 0) return HALO_OK;
+    const std::vector<uint64_t> &tbl = urs_table();
+    std::vector<uint64_t> canon(4 * n);
+    for (size_t i = 0; i < n; ++i) {
+        host::Fr s = host::urs_scalar(first_index + i).from_mont();
+        s.store(&canon[4 * i]);
+    }
+    uint64_t *d_tbl = nullptr, *d_canon = nullptr;
+    HALO_HIP(hipMalloc(&d_tbl, tbl.size() * 8));
+    HALO_HIP(hipMalloc(&d_canon, canon.size() * 8));
+    HALO_HIP(hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipMemcpyAsync(d_canon, canon.data(), canon.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, d_tbl, reinterpret_cast<const uint32_t *>(d_canon), (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(d_tbl);
+    hipFree(d_canon);
+    return HALO_OK;
+}
+
+// ------------------------------------------------------------------------------ workspace
+static size_t max_counts() { return (size_t)16 * 32768; }  // c = 16 is the largest W*B over c in [4, 16]
+
+int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
+    MsmWorkspace &ws = ctx->ws;
+    if (n < 64) n = 64;
+    ws.cap_n = n;
+    size_t cnt = 0, srt = 0;
+    for (size_t m = 1; m <= n; m <<= 1) {
+        for (int c = 4; c <= 16; ++c) {
+            MsmPlan p = msm_plan(m, c);
+            if (ctx->window_bits == 0 && c != msm_plan(m, 0).c && c != 16) continue;
+            size_t tb = (size_t)p.W * p.B;
+            if (tb > cnt) cnt = tb;
+        }
+    }
+    if (cnt > max_counts()) cnt = max_counts();
+    srt = n * 64;  // W <= 64
+    // tighter: for the automatic plan W shrinks as n grows; keep n*W of the worst automatic plan
+    size_t worst = 0;
+    for (size_t m = 1; m <= n; m <<= 1) {
+        size_t mm = m * 2 - 1 < n ? m * 2 - 1 : n;
+        MsmPlan p = msm_plan(m, 0);
+        if (mm * p.W > worst) worst = mm * (size_t)p.W;
+    }
+    if (worst < srt) srt = worst;
+    if (srt < n * 22) srt = n * 22;  // room for forced c >= 12
+    ws.cap_counts = max_counts();
+    ws.cap_sorted = srt;
+    HALO_HIP(hipMalloc(&ws.d_canon, n * 32));
+    HALO_HIP(hipMalloc(&ws.d_counts, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_starts, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_cursor, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
+    HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
+    HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_counts * 128));
+    HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 32 * 8));
+    HALO_HIP(hipMalloc(&ws.d_winsum, (size_t)64 * 12 * 8));
+    HALO_HIP(hipHostMalloc(&ws.h_winsum, (size_t)64 * 12 * 8));
+    return HALO_OK;
+}
+void msm_workspace_free(halo_ctx *ctx) {
+    MsmWorkspace &ws = ctx->ws;
+    hipFree(ws.d_canon); hipFree(ws.d_counts); hipFree(ws.d_starts); hipFree(ws.d_cursor); hipFree(ws.d_blockoff);
+    hipFree(ws.d_sorted); hipFree(ws.d_buckets); hipFree(ws.d_seg); hipFree(ws.d_winsum);
+    if (ws.h_winsum) hipHostFree(ws.h_winsum);
+    ws = MsmWorkspace();
+}
+
+// ------------------------------------------------------------------------------ driver
+int msm_run(halo_ctx *ctx, const uint64_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, host::Point *out) {
+    *out = host::Point::infinity();
+    if (n == 0) return HALO_OK;
+    MsmWorkspace &ws = ctx->ws;
+    if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
+    MsmPlan p = msm_plan(n, ctx->window_bits);
+    size_t total = (size_t)p.W * p.B;
+    if (total > ws.cap_counts || n * (size_t)p.W > ws.cap_sorted) { set_error("msm: window plan exceeds workspace"); return HALO_E_ARG; }
+    hipStream_t s = ctx->stream;
+    HALO_HIP(hipMemsetAsync(ws.d_counts, 0, total * 4, s));
+    HALO_HIP(hipMemsetAsync(ws.d_cursor, 0, total * 4, s));
+    dim3 gridn((unsigned)((n + 255) / 256)), b256(256);
+    HALO_LAUNCH(ctx, "k_msm_count", k_msm_count, gridn, b256, 0, d_scalars, mont ? 1 : 0, (uint32_t)n, p.c, p.W, p.B, ws.d_canon,
+                ws.d_counts);
+    uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
+    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
+    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
+    HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridn, b256, 0, ws.d_canon, (uint32_t)n, p.c, p.W, p.B, ws.d_starts, ws.d_blockoff,
+                ws.d_cursor, ws.d_sorted);
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, dim3((unsigned)((total + 255) / 256)), b256, 0, d_bases, ws.d_sorted,
+                ws.d_starts, ws.d_blockoff, ws.d_counts, (uint32_t)total, ws.d_buckets);
+    uint32_t L, nseg;
+    int logL = 0;
+    if (p.B <= 512) { nseg = 1; L = p.B >= 64 ? p.B / 64 : 1; }
+    else { L = 8; nseg = p.B / 512; }
+    while ((1u << logL) < L) logL++;
+    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, p.B, L, logL, nseg, ws.d_seg);
+    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)p.W), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)p.W * 96, hipMemcpyDeviceToHost, s));
+    HALO_HIP(hipStreamSynchronize(s));
+    if (ctx->prof.on) ctx->prof.collect();
+    host::Point acc = host::Point::infinity();
+    for (int w = p.W - 1; w >= 0; --w) {
+        if (!acc.is_inf())
+            for (int k = 0; k < p.c; ++k) acc = acc.dbl();
+        acc = acc + host::Point::load(ws.h_winsum + 12 * (size_t)w);
+    }
+    *out = acc;
+    return HALO_OK;
+}
+
+}  // namespace halo

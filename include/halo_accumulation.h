@@ -1,0 +1,121 @@
+/* halo_accumulation.h -- C ABI of the MI355X (gfx950) MSM / IPA hot path.
+ *
+ * Drop-in boundary for rasmus-kirk/halo-accumulation's `group.rs` function set plus the
+ * fold loop of `pcdl::open`.  The reference has no FFI seam of its
+ * own; each entry point below names the reference code (file:line under code/src/) that a
+ * Rust shim would replace with a call to it (the shim is shown in INTEGRATION.md).
+ *
+ * Data conventions -- exactly what arkworks keeps in memory, so a shim passes `x.0.0`:
+ *   scalar (Fr)   4 x u64, little-endian limbs, Montgomery form (R = 2^256)
+ *   affine base   8 x u64 = x limbs | y limbs (Fq Montgomery).  (0,0) = point at infinity
+ *   Jacobian pt  12 x u64 = X | Y | Z (Fq Montgomery), what `Projective::new_unchecked`
+ *                takes (consts.rs:13-21).  Z = 0 = infinity.
+ *   Every point WRITTEN by the library is normalised: (x, y, 1), or (1, 1, 0) for infinity,
+ *   so outputs are bit-reproducible run to run.
+ *
+ * Errors: 0 = ok, negative = HALO_E_*; halo_last_error() returns a thread-local message.
+ * A shim maps HALO_E_ASSERT to panic! (the reference's assert!, pcdl.rs:102-104,130-132,
+ * pedersen.rs:7-12) and HALO_E_REJECT to anyhow::Error (its ensure!, pcdl.rs:261-262,
+ * 307-310,339; acc.rs:152-155,169,237-240).
+ *
+ * Ownership: inputs are borrowed for the call; outputs go to caller buffers; only ctx / ipa
+ * handles are library-owned.  A ctx is bound to one HIP device and one stream: calls on the
+ * same ctx must not overlap; different ctxs are independent.  No global init.
+ * There is NO CPU fallback: without a gfx950 device every compute entry point fails with
+ * HALO_E_DEVICE.
+ */
+#ifndef HALO_ACCUMULATION_H
+#define HALO_ACCUMULATION_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALO_OK 0
+#define HALO_E_ASSERT (-1) /* reference would panic (assert!) */
+#define HALO_E_REJECT (-2) /* reference would return Err (ensure!) */
+#define HALO_E_ARG (-3)    /* bad pointer / size for this library */
+#define HALO_E_DEVICE (-4) /* HIP / RCCL failure, or no GPU */
+
+typedef struct halo_ctx halo_ctx;
+typedef struct halo_ipa halo_ipa;
+
+const char *halo_last_error(void);
+int halo_device_count(void);
+
+/* ---- context: the commitment key, device resident (consts.rs:23-24,68: N, GS) ---------- */
+/* Upload n affine bases (n x 8 limbs). */
+int halo_ctx_create(int device, const uint64_t *bases_affine, size_t n, halo_ctx **out);
+/* Derive G_i = [SHA3-256(genesis || LE64(first_index + i)) mod r] * (-1, 2) on the device
+ * (main.rs:18-45; GS[i] of consts.rs is first_index = 2).  Hashing on host, scalar-mul in HIP. */
+int halo_ctx_create_urs(int device, uint64_t first_index, size_t n, halo_ctx **out);
+void halo_ctx_destroy(halo_ctx *ctx);
+size_t halo_ctx_size(const halo_ctx *ctx);
+/* copy bases [off, off+n) back to the host (n x 8 limbs) */
+int halo_ctx_read_bases(halo_ctx *ctx, size_t off, size_t n, uint64_t *out_affine);
+/* device pointer of the base table and the ctx's hipStream_t (for callers holding device memory) */
+void *halo_ctx_bases_dev(halo_ctx *ctx);
+void *halo_ctx_stream(halo_ctx *ctx);
+/* S = hash(0), H = hash(1) of main.rs:35-45 as normalised Jacobian limbs (host computed) */
+int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
+
+/* ---- group.rs ------------------------------------------------------------------------- */
+/* point_dot_affine (group.rs:24-26): sum_i scalars[i] * GS[off + i], Pippenger in HIP. */
+int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
+/* same, scalars already in device memory (n x 4 limbs, 32-byte aligned device pointer) */
+int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int scalars_are_mont, uint64_t out_jac[12]);
+/* point_dot (group.rs:18-21): arbitrary Jacobian points (m x 12 limbs); they are brought to
+ * affine with one batched inversion instead of the reference's m separate ones. */
+int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out_jac[12]);
+/* scalar_dot (group.rs:13-15) */
+int halo_scalar_dot(halo_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t m, uint64_t out[4]);
+/* construct_powers (group.rs:29-37): [1, z, ..., z^(n-1)] */
+int halo_powers(halo_ctx *ctx, const uint64_t z[4], size_t n, uint64_t *out);
+/* DensePolynomial::evaluate as called at pcdl.rs:135 */
+int halo_poly_eval(halo_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t z[4], uint64_t out[4]);
+
+/* ---- pcdl.rs: h(X) -------------------------------------------------------------------- */
+/* HPoly::get_poly().coeffs (pcdl.rs:56-77): 2^lg_n coefficients from xis[0..lg_n] (xis[0] unused) */
+int halo_h_coeffs(halo_ctx *ctx, const uint64_t *xis, size_t lg_n, uint64_t *out);
+/* pedersen::commit(None, GS[0..2^lg_n], h.get_poly().coeffs) of pcdl.rs:338, fused on device */
+int halo_h_commit(halo_ctx *ctx, const uint64_t *xis, size_t lg_n, uint64_t out_jac[12]);
+/* HPoly::eval (pcdl.rs:79-91) for m polynomials at one point (acc.rs:102-104) */
+int halo_h_eval_batch(halo_ctx *ctx, const uint64_t *xis, size_t m, size_t lg_n, const uint64_t z[4], uint64_t *out);
+/* AccumulatedHPolys::get_poly (acc.rs:85-94): out = h0 (2 coeffs) + sum_i alphas[i] * h_i(X) */
+int halo_h_accumulate(halo_ctx *ctx, const uint64_t *h0, const uint64_t *xis, const uint64_t *alphas, size_t m,
+                      size_t lg_n, uint64_t *out);
+
+/* ---- pcdl.rs:183-231: the IPA halving loop, state device resident ------------------------ */
+/* G = GS[0..n), c = coeffs zero-padded to n, z-powers of z (pcdl.rs:183-186) */
+int halo_ipa_begin(halo_ctx *ctx, size_t n, const uint64_t *coeffs, size_t len, const uint64_t z[4], halo_ipa **out);
+/* L = <c_r, G_l> + <c_r, z_l> H', R = <c_l, G_r> + <c_l, z_r> H'   (pcdl.rs:203-208) */
+int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], uint64_t R[12]);
+/* G, c, z folds with the challenge the host hashed from (xi_prev, L, R)   (pcdl.rs:216-224) */
+int halo_ipa_round_fold(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_inv[4]);
+/* U = G[0], c = c[0]   (pcdl.rs:230-231) */
+int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]);
+void halo_ipa_destroy(halo_ipa *st);
+size_t halo_ipa_len(const halo_ipa *st);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------- */
+/* When enabled, every kernel launch on this ctx is bracketed by hipEvents on the ctx stream. */
+int halo_prof_enable(halo_ctx *ctx, int on);
+int halo_prof_reset(halo_ctx *ctx);
+/* number of distinct kernels seen; name/total ms/launch count of entry i */
+int halo_prof_count(halo_ctx *ctx);
+int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
+/* MSM tuning: window bits (0 = automatic) */
+int halo_set_window_bits(halo_ctx *ctx, int c);
+
+/* ---- primitive hooks used by the parity tests (elementwise over n) ----------------------- */
+int halo_test_field_op(halo_ctx *ctx, int field /*0 Fq, 1 Fr*/, int op /*0 mul,1 add,2 sub,3 inv,4 from_mont,5 to_mont*/,
+                       const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
+/* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs) */
+int halo_test_point_op(halo_ctx *ctx, int op, const uint64_t *a_jac, const uint64_t *b, size_t n, uint64_t *out_jac);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Bit-exactness is defined on canonical affine coordinates (x, y mod p) or the infinity flag
+(SURVEY.md section 7); the library additionally normalises what it writes, so Jacobian
+outputs are compared limb-for-limb where the oracle normalises too.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import orc
+import pallas_model as pm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hal():
+    import halo_accumulation_amd as h
+    return h._lib
+
+
+@pytest.fixture(scope="module")
+def ctx16k(hal):
+    """The reference's own key size: N = 16384 (consts.rs:23), derived on the GPU."""
+    c = hal.Context(urs_n=16384)
+    yield c
+    c.close()
+
+
+def canon(j):
+    return orc.point_canonical(j)
+
+
+# ------------------------------------------------------------------ K11 + group law
+def test_urs_kernel_reproduces_consts_table(ctx16k, kat):
+    """All 16,384 GS entries of consts.rs, bit-for-bit, out of the HIP fixed-base kernel."""
+    gs = ctx16k.read_bases()
+    assert hashlib.sha256(gs.tobytes()).hexdigest() == kat["GS_mont_limbs_sha256"]
+
+
+def test_field_ops(ctx16k):
+    n = 4096
+    a, s = orc.rng_scalars(1, n)
+    b, _ = orc.rng_scalars(s, n)
+    edge = [0, 1, pm.R_ORDER - 1, pm.MONT_R % pm.R_ORDER, 2, pm.R_ORDER - 2, (1 << 254) % pm.R_ORDER]
+    for i, e in enumerate(edge):
+        a[i] = orc.fr_to_mont(e)
+        b[(i + 3) % len(edge)] = orc.fr_to_mont(e)
+    for field, mod in ((1, pm.R_ORDER), (0, pm.P)):
+        # the same limb patterns are valid elements of both fields (all < 2^254 + small): reduce for Fq
+        A = [int.from_bytes(x.tobytes(), "little") % mod for x in a]
+        B = [int.from_bytes(x.tobytes(), "little") % mod for x in b]
+        am = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in A], dtype=np.uint64)
+        bm = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in B], dtype=np.uint64)
+        rinv = pm.inv_mod(pm.MONT_R, mod)
+        ints = lambda arr: [int.from_bytes(x.tobytes(), "little") for x in arr]
+        assert ints(ctx16k.field_op(field, 0, am, bm)) == [x * y * rinv % mod for x, y in zip(A, B)]
+        assert ints(ctx16k.field_op(field, 1, am, bm)) == [(x + y) % mod for x, y in zip(A, B)]
+        assert ints(ctx16k.field_op(field, 2, am, bm)) == [(x - y) % mod for x, y in zip(A, B)]
+        assert ints(ctx16k.field_op(field, 4, am)) == [x * rinv % mod for x in A]
+        assert ints(ctx16k.field_op(field, 5, am)) == [x * pm.MONT_R % mod for x in A]
+        inv = ints(ctx16k.field_op(field, 3, am[:256]))
+        # Montgomery inverse: (xR)^-1 R^2 ... the kernel returns a^(p-2) in Montgomery arithmetic = a^-1 * R^2 / R
+        for x, got in zip(A[:256], inv):
+            if x == 0:
+                assert got == 0
+            else:
+                assert got * x * rinv % mod == pm.MONT_R % mod  # got (*) x == one
+
+
+def test_point_ops(ctx16k, urs4096):
+    n = 512
+    ks, s = orc.rng_scalars(77, n)
+    # a_i = k_i * G_i (Jacobian, un-normalised on purpose: scale by lambda^2, lambda^3)
+    a = np.zeros((n, 12), dtype=np.uint64)
+    b = np.zeros((n, 12), dtype=np.uint64)
+    for i in range(n):
+        orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(a[i]))
+        orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i + n]), orc.ptr(b[i]))
+    # special cases: P + P, P + (-P), inf + P, P + inf
+    b[0] = a[0]
+    neg = orc.z(12); orc.lib().orc_point_mul(orc.ptr(a[1]), orc.ptr(orc.fr_to_mont(pm.R_ORDER - 1)), orc.ptr(neg)); b[1] = neg
+    inf = np.array([1, 0, 0, 0] * 0 + list(a[2][:8]) + [0, 0, 0, 0], dtype=np.uint64)
+    a[2] = inf
+    b[3] = inf
+    got = ctx16k.point_op(0, a, b)
+    for i in range(n):
+        want = orc.z(12); orc.lib().orc_point_add(orc.ptr(a[i]), orc.ptr(b[i]), orc.ptr(want))
+        assert canon(got[i]) == canon(want), i
+    assert canon(got[1]) is None and canon(got[2]) == canon(b[2]) and canon(got[3]) == canon(a[3])
+    # mixed add (XYZZ and Jacobian forms must agree inside the kernel) incl. P + P and P + (-P)
+    baff = np.ascontiguousarray(urs4096[n:2 * n].copy())
+    baff[0] = urs4096[0]
+    baff[1] = urs4096[1]; baff[1, 4:] = np.array([(pm.P - orc.fq_from_mont(urs4096[1, 4:])) * pm.MONT_R % pm.P >> (64 * k) & (2**64 - 1) for k in range(4)], dtype=np.uint64)
+    baff[4] = 0  # affine infinity
+    a2 = a.copy(); a2[2] = inf
+    got = ctx16k.point_op(1, a2, baff)
+    for i in range(n):
+        bj = orc.z(12); orc.lib().orc_affine_to_jac(orc.ptr(baff[i]), orc.ptr(bj))
+        want = orc.z(12); orc.lib().orc_point_add(orc.ptr(a2[i]), orc.ptr(bj), orc.ptr(want))
+        assert canon(got[i]) == canon(want), i
+    got = ctx16k.point_op(2, a2)
+    for i in range(n):
+        want = orc.z(12); orc.lib().orc_point_add(orc.ptr(a2[i]), orc.ptr(a2[i]), orc.ptr(want))
+        assert canon(got[i]) == canon(want), i
+    ks[5] = 0; ks[6] = orc.fr_to_mont(1); ks[7] = orc.fr_to_mont(pm.R_ORDER - 1)
+    got = ctx16k.point_op(3, a, ks)
+    for i in range(64):
+        want = orc.z(12); orc.lib().orc_point_mul(orc.ptr(a[i]), orc.ptr(ks[i]), orc.ptr(want))
+        assert canon(got[i]) == canon(want), i
+
+
+# ------------------------------------------------------------------ K1/K2 MSM
+EDGE = [0, 1, pm.R_ORDER - 1, 1 << 254, 2, pm.R_ORDER - 2]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 63, 64, 65, 256, 1000, 4096, 16384])
+def test_msm_vs_oracle(ctx16k, n):
+    gs = ctx16k.read_bases(0, n)
+    sc, _ = orc.rng_scalars(0x48414C4F00000002 + n, n)
+    for i, e in enumerate(EDGE[: min(n, len(EDGE))]):
+        sc[(i * 7) % n] = orc.fr_to_mont(e)
+    want = orc.msm_affine(gs, sc)
+    got = ctx16k.msm(sc)
+    assert canon(got) == canon(want)
+    assert got.tolist() == want.tolist()  # both sides normalise: limb-exact
+    # canonical (non-Montgomery) scalars give the same answer
+    sc_canon = np.array([[(orc.fr_from_mont(s) >> (64 * k)) & (2**64 - 1) for k in range(4)] for s in sc[: min(n, 256)]], dtype=np.uint64)
+    if n <= 256:
+        assert ctx16k.msm(sc_canon, mont=False).tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("c", [4, 7, 9, 12, 13, 16])
+def test_msm_every_window_size(ctx16k, c):
+    n = 2048
+    gs = ctx16k.read_bases(100, n)
+    sc, _ = orc.rng_scalars(c, n)
+    want = orc.msm_affine(gs, sc)
+    ctx16k.set_window_bits(c)
+    try:
+        assert ctx16k.msm(sc, off=100).tolist() == want.tolist()
+    finally:
+        ctx16k.set_window_bits(0)
+
+
+def test_msm_degenerate_inputs(ctx16k):
+    n = 4096
+    gs = ctx16k.read_bases(0, n)
+    G = None
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    assert canon(ctx16k.msm(zero)) is None
+    for val in (1, pm.R_ORDER - 1):
+        sc = np.ascontiguousarray(np.tile(orc.fr_to_mont(val), (n, 1)))
+        assert ctx16k.msm(sc).tolist() == orc.msm_affine(gs, sc).tolist()
+    sc, _ = orc.rng_scalars(5, n)
+    sc[::2] = 0  # 50 % zeros
+    assert ctx16k.msm(sc).tolist() == orc.msm_affine(gs, sc).tolist()
+    # pcdl::commit of a linear polynomial: n - 2 zero scalars (acc.rs:195)
+    lin = np.zeros((n, 4), dtype=np.uint64); lin[:2] = sc[1:3]
+    assert ctx16k.msm(lin).tolist() == orc.msm_affine(gs, lin).tolist()
+
+
+def test_msm_all_same_base_and_cancellation(hal, urs4096):
+    n = 1024
+    same = np.ascontiguousarray(np.tile(urs4096[5], (n, 1)))
+    c = hal.Context(same)
+    try:
+        sc, _ = orc.rng_scalars(9, n)
+        assert c.msm(sc).tolist() == orc.msm_affine(same, sc).tolist()   # buckets full of P + P
+        sc[1] = orc.fr_to_mont(pm.R_ORDER - orc.fr_from_mont(sc[0]))
+        assert canon(c.msm(sc[:2])) is None                              # P + (-P)
+        one = np.ascontiguousarray(np.tile(orc.fr_to_mont(1), (n, 1)))
+        assert c.msm(one).tolist() == orc.msm_affine(same, one).tolist()
+    finally:
+        c.close()
+
+
+def test_msm_points_matches_point_dot(ctx16k, urs4096):
+    """group.rs:18-21: arbitrary Jacobian inputs, zip-to-min semantics."""
+    m = 300
+    pts = np.zeros((m, 12), dtype=np.uint64)
+    ks, s = orc.rng_scalars(31, m)
+    for i in range(m):
+        j = orc.z(12); orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(j))
+        # un-normalise: multiply by a scalar so Z != 1 through the oracle's own routine? keep Z = 1 for most,
+        pts[i] = j
+    pts[7] = np.array(list(pts[7][:8]) + [0, 0, 0, 0], dtype=np.uint64)  # infinity
+    sc, _ = orc.rng_scalars(s, m + 5)
+    want = orc.msm_jac(pts, sc[:m])
+    assert ctx16k.msm_points(pts, sc).tolist() == want.tolist()
+
+
+# ------------------------------------------------------------------ full size (BASELINE config 2)
+@pytest.fixture(scope="module")
+def ctx1m(hal):
+    c = hal.Context(urs_n=1 << 20)
+    yield c
+    c.close()
+
+
+def test_urs_extension_prefix_is_consts_table(ctx1m, kat):
+    gs = ctx1m.read_bases(0, kat["GS_count"])
+    assert hashlib.sha256(gs.tobytes()).hexdigest() == kat["GS_mont_limbs_sha256"]
+
+
+def test_msm_2_20_vs_oracle(ctx1m):
+    n = 1 << 20
+    sc, _ = orc.rng_scalars(0x48414C4F00000002, n)
+    gs = ctx1m.read_bases()
+    got = ctx1m.msm(sc)
+    want = orc.msm_affine(gs, sc)  # ~6 s of single-thread CPU
+    assert got.tolist() == want.tolist()
+
+
+def test_msm_2_20_linearity(ctx1m):
+    """Size-independent property: msm(a) + msm(b) == msm(a + b); msm(k a) == k msm(a)."""
+    n = 1 << 20
+    a, s = orc.rng_scalars(123, n)
+    b, _ = orc.rng_scalars(s, n)
+    ai = a.view(np.uint64)
+    # a + b in Fr via the GPU's own field op would be circular: add on the host with numpy big-int-free trick:
+    # use the oracle for the elementwise sum (fast C loop through ctypes is too slow for 2^20) -> use k = 2: a + a
+    two_a = ctx1m.field_op(1, 1, a[: 1 << 14], a[: 1 << 14])  # checked against the model in test_field_ops
+    pa = ctx1m.msm(a[: 1 << 14])
+    p2a = ctx1m.msm(two_a)
+    want = orc.z(12); orc.lib().orc_point_add(orc.ptr(pa), orc.ptr(pa), orc.ptr(want))
+    assert p2a.tolist() == want.tolist()
+    # split linearity at full size: msm over [0, n) == msm over [0, n/2) + msm over [n/2, n)
+    full = ctx1m.msm(a)
+    lo = ctx1m.msm(a[: n // 2])
+    hi = ctx1m.msm(a[n // 2:], off=n // 2)
+    want = orc.z(12); orc.lib().orc_point_add(orc.ptr(lo), orc.ptr(hi), orc.ptr(want))
+    assert full.tolist() == want.tolist()
