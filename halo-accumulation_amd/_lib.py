@@ -63,6 +63,18 @@ _SIGS = {
     "halo_ipa_finish": (C.c_int, [C.c_void_p, u64p, u64p]),
     "halo_ipa_destroy": (None, [C.c_void_p]),
     "halo_ipa_len": (C.c_size_t, [C.c_void_p]),
+    "halo_proof_words": (C.c_size_t, [C.c_size_t]),
+    "halo_instance_words": (C.c_size_t, [C.c_size_t]),
+    "halo_accumulator_words": (C.c_size_t, [C.c_size_t]),
+    "halo_pedersen_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
+    "halo_pcdl_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
+    "halo_pcdl_open": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_pcdl_succinct_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p]),
+    "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_acc_prover": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p, C.c_size_t, u64p]),
+    "halo_acc_verifier": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]),
+    "halo_acc_decider": (C.c_int, [C.c_void_p, u64p]),
+    "halo_random_instance": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p]),
     "halo_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_prof_reset": (C.c_int, [C.c_void_p]),
     "halo_prof_count": (C.c_int, [C.c_void_p]),

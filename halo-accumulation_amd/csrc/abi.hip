@@ -83,18 +83,42 @@ static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
         if (_e != hipSuccess) return halo::hip_fail(_e, "hipSetDevice"); \
     } while (0)
 
-static int upload(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) {
+int upload_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) {
     if (words == 0) return HALO_OK;
     HALO_HIP(hipMemcpyAsync(dst, src, words * 8, hipMemcpyHostToDevice, ctx->stream));
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     return HALO_OK;
 }
-static int download(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) {
+int download_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) {
     if (words == 0) return HALO_OK;
     HALO_HIP(hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToHost, ctx->stream));
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     return HALO_OK;
 }
+
+
+int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out) {
+    halo_ipa *st = new (std::nothrow) halo_ipa();
+    if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
+    st->ctx = ctx;
+    st->n = st->m = n;
+    int rc = HALO_OK;
+    do {
+        if (hipMalloc(&st->d_G, n * 64) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
+            hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
+        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 64, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
+        }
+        rc = fr_powers(ctx, z, n, st->d_z);
+    } while (0);
+    if (rc) { halo_ipa_destroy(st); return rc; }
+    *out = st;
+    return HALO_OK;
+}
+
+static int upload(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) { return upload_words(ctx, dst, src, words); }
+static int download(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) { return download_words(ctx, dst, src, words); }
 
 }  // namespace halo
 
@@ -143,6 +167,8 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_tmp_a);
     (void)hipFree(ctx->d_tmp_b);
     (void)hipFree(ctx->d_tmp_c);
+    (void)hipFree(ctx->d_poly);
+    (void)hipFree(ctx->d_poly2);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -301,23 +327,10 @@ int halo_ipa_begin(halo_ctx *ctx, size_t n, const uint64_t *coeffs, size_t len, 
     if (!is_pow2(n)) { set_error("ipa_begin: n is not a power of two"); return HALO_E_ASSERT; }  // pcdl.rs:130
     if (n > ctx->n) { set_error("ipa_begin: n exceeds the commitment key (d <= D)"); return HALO_E_ASSERT; }  // pcdl.rs:132
     if (len > n) { set_error("ipa_begin: more coefficients than n (p.degree() <= d)"); return HALO_E_ASSERT; }  // pcdl.rs:131
-    halo_ipa *st = new (std::nothrow) halo_ipa();
-    if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
-    st->ctx = ctx;
-    st->n = st->m = n;
-    int rc = HALO_OK;
-    do {
-        if (hipMalloc(&st->d_G, n * 64) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
-            hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
-        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 64, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-            hipMemsetAsync(st->d_c, 0, n * 32, ctx->stream) != hipSuccess) { set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break; }
-        rc = upload(ctx, st->d_c, coeffs, len * 4);
-        if (rc) break;
-        rc = fr_powers(ctx, host::Fr::load(z), n, st->d_z);
-    } while (0);
-    if (rc) { halo_ipa_destroy(st); return rc; }
-    *out = st;
-    return HALO_OK;
+    HALO_HIP(hipMemsetAsync(ctx->d_tmp_a, 0, n * 32, ctx->stream));
+    int rc = upload(ctx, ctx->d_tmp_a, coeffs, len * 4);
+    if (rc) return rc;
+    return ipa_begin_dev(ctx, n, ctx->d_tmp_a, host::Fr::load(z), out);
 }
 
 int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], uint64_t R[12]) {

@@ -82,6 +82,8 @@ struct halo_ctx {
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
+    // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover
+    uint64_t *d_poly = nullptr, *d_poly2 = nullptr;
 };
 
 struct halo_ipa {
@@ -115,5 +117,14 @@ int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host
 // d_out[k] (+)= scale * prod_{bit i of k} xis[lg_n - i]
 int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr &scale, bool accumulate, uint64_t *d_out);
 int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out);
+// SplitMix64 stream -> n Montgomery scalars (element i = draws 4i+1..4i+4 after state0)
+int rng_scalars_dev(halo_ctx *ctx, uint64_t state0, size_t n, uint64_t *d_out);
+int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, uint64_t *d_out);
+int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a);
+
+// ---- abi.hip (device-pointer forms used by pcdl_acc.hip)
+int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out);
+int upload_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words);
+int download_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words);
 
 }  // namespace halo

@@ -178,6 +178,62 @@ __global__ __launch_bounds__(256) void k_h_eval(const uint64_t *__restrict__ xis
     fe_store(out + 4 * (size_t)i, v);
 }
 
+
+// ------------------------------------------------------------------ input generator / polynomial helpers
+// SplitMix64 is counter based: draw k of a stream with state s0 is mix(s0 + k*gamma), so the
+// scalars of `PallasPoly::rand` (pcdl.rs:141) can be produced in parallel, bit-identical to a
+// sequential host stream.  Element i uses draws 4i+1 .. 4i+4, reduced mod r, to Montgomery form.
+HALO_DEV uint64_t splitmix_at(uint64_t s0, uint64_t k) {
+    uint64_t z = s0 + k * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_rng_scalars(uint64_t s0, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe v;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t w = splitmix_at(s0, 4 * (uint64_t)i + k + 1);
+        v.v[2 * k] = (uint32_t)w;
+        v.v[2 * k + 1] = (uint32_t)(w >> 32);
+    }
+    // 2^256 < 4r: at most three subtractions
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) {
+        uint32_t d[8];
+        uint64_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t t = (uint64_t)v.v[k] - FrCfg::P[k] - br;
+            d[k] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        if (!br) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v.v[k] = d[k];
+        }
+    }
+    fe_store(out + 4 * (size_t)i, fe_to_mont<FrCfg>(v));
+}
+// p_bar = q * (X - z): p_bar[i] = q[i-1] - z q[i], i in [0, deg]; q has deg coefficients (pcdl.rs:140-142)
+__global__ __launch_bounds__(256) void k_pbar(const uint64_t *__restrict__ q, uint32_t deg, FeArg zarg, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > deg) return;
+    Fe z = from_arg(zarg);
+    Fe lo = (i >= 1) ? fe_load(q + 4 * (size_t)(i - 1)) : fe_zero();
+    Fe hi = (i < deg) ? fe_load(q + 4 * (size_t)i) : fe_zero();
+    fe_store(out + 4 * (size_t)i, fe_sub<FrCfg>(lo, fe_mul<FrCfg>(z, hi)));
+}
+// y[i] += a * x[i]   (p' = p + alpha p_bar, pcdl.rs:156)
+__global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const uint64_t *__restrict__ x, uint32_t n, FeArg aarg) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe a = from_arg(aarg);
+    fe_store(y + 4 * (size_t)i, fe_add<FrCfg>(fe_load(y + 4 * (size_t)i), fe_mul<FrCfg>(a, fe_load(x + 4 * (size_t)i))));
+}
+
 // ================================================================== host launchers
 int ipa_fold_points(halo_ctx *ctx, uint64_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
@@ -292,6 +348,24 @@ int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr
 int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out) {
     if (m == 0) return HALO_OK;
     HALO_LAUNCH(ctx, "k_h_eval", k_h_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_xis, (uint32_t)m, (int)lg_n, to_arg(z), d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int rng_scalars_dev(halo_ctx *ctx, uint64_t state0, size_t n, uint64_t *d_out) {
+    if (n == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_rng_scalars", k_rng_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, state0, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, uint64_t *d_out) {
+    HALO_LAUNCH(ctx, "k_pbar", k_pbar, dim3((unsigned)((deg + 1 + 255) / 256)), dim3(256), 0, d_q, (uint32_t)deg, to_arg(z), d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a) {
+    if (n == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_axpy", k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_y, d_x, (uint32_t)n, to_arg(a));
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

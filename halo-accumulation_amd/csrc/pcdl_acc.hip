@@ -1,0 +1,495 @@
+// Host side above the kernels: the reference's `pedersen`, `pcdl` and `acc` modules with the
+// same names, argument meaning and error behaviour (pedersen.rs:6-20, pcdl.rs:99-342,
+// acc.rs:135-255), every linear-time step running in HIP.  The reference is Rust and there is
+// no Rust toolchain in this image, so this layer is C++ behind a C ABI; INTEGRATION.md shows
+// the Rust shim that would sit on the group.rs-level entry points instead.
+//
+// What stays on the host, exactly as in the reference: Fiat-Shamir hashing (rho_0!/rho_1!),
+// challenge inversion, the O(lg n) succinct check and the struct packing.
+#include <memory>
+
+#include "internal.hpp"
+
+namespace halo {
+
+using host::Fr;
+using host::Point;
+using host::Transcript;
+
+// ---- flat layouts (include/halo_accumulation.h, "pcdl / acc level")
+static size_t proof_words(size_t lg) { return 2 + 24 * lg + 32; }
+static size_t instance_words(size_t lg) { return 21 + proof_words(lg); }
+static size_t acc_words(size_t lg) { return instance_words(lg) + 24; }
+static uint64_t *pf_L(uint64_t *pf, size_t i) { return pf + 2 + 12 * i; }
+static uint64_t *pf_R(uint64_t *pf, size_t lg, size_t i) { return pf + 2 + 12 * lg + 12 * i; }
+static uint64_t *pf_U(uint64_t *pf, size_t lg) { return pf + 2 + 24 * lg; }
+static uint64_t *pf_c(uint64_t *pf, size_t lg) { return pf + 2 + 24 * lg + 12; }
+static uint64_t *pf_Cbar(uint64_t *pf, size_t lg) { return pf + 2 + 24 * lg + 16; }
+static uint64_t *pf_wp(uint64_t *pf, size_t lg) { return pf + 2 + 24 * lg + 28; }
+
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static size_t ilog2(size_t n) { size_t l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
+static int fail_assert(const char *m) { set_error(m); return HALO_E_ASSERT; }
+static int fail_reject(const char *m) { set_error(m); return HALO_E_REJECT; }
+
+struct PublicPoints { Point S, H; };
+static const PublicPoints &public_points() {  // main.rs:35-45 / consts.rs:26-65
+    static PublicPoints pp = [] {
+        Point g = Point::generator();
+        return PublicPoints{g.mul(host::urs_scalar(0)).normalized(), g.mul(host::urs_scalar(1)).normalized()};
+    }();
+    return pp;
+}
+
+static Fr rho0_C_z_v(const Point &C, const Fr &z, const Fr &v) {
+    Transcript t; t.point(C); t.scalar(z); t.scalar(v); return t.finish(0);
+}
+static Fr rho0_C_z_v_Cbar(const Point &C, const Fr &z, const Fr &v, const Point &Cb) {
+    Transcript t; t.point(C); t.scalar(z); t.scalar(v); t.point(Cb); return t.finish(0);
+}
+static Fr rho0_xi_L_R(const Fr &xi, const Point &L, const Point &R) {
+    Transcript t; t.scalar(xi); t.point(L); t.point(R); return t.finish(0);
+}
+
+static int ensure_poly_buffers(halo_ctx *ctx) {
+    size_t n = ctx->n < 64 ? 64 : ctx->n;
+    if (!ctx->d_poly) HALO_HIP(hipMalloc(&ctx->d_poly, n * 32));
+    if (!ctx->d_poly2) HALO_HIP(hipMalloc(&ctx->d_poly2, n * 32));
+    return HALO_OK;
+}
+
+static size_t host_poly_degree(const uint64_t *coeffs, size_t len) {  // DensePolynomial::degree
+    size_t d = 0;
+    for (size_t i = 0; i < len; ++i)
+        if (coeffs[4 * i] | coeffs[4 * i + 1] | coeffs[4 * i + 2] | coeffs[4 * i + 3]) d = i;
+    return d;
+}
+
+// pedersen::commit over GS[0..n) for device-resident, zero-padded scalars (pedersen.rs:6-20)
+static int pedersen_commit_dev(halo_ctx *ctx, const Fr *w, const uint64_t *d_ms, size_t n, Point *out) {
+    Point acc;
+    int rc = msm_run(ctx, ctx->d_bases, d_ms, true, n, &acc);
+    if (rc) return rc;
+    if (w) acc = public_points().S.mul(*w) + acc;
+    *out = acc;
+    return HALO_OK;
+}
+
+// pcdl::commit for a short host polynomial (acc.rs:153,195: two coefficients): same point, no launch
+static int commit_short_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, const Fr *w, Point *out) {
+    std::vector<uint64_t> bases(8 * len);
+    int rc = download_words(ctx, bases.data(), ctx->d_bases, 8 * len);
+    if (rc) return rc;
+    std::vector<Point> pts(len);
+    std::vector<Fr> ks(len);
+    for (size_t i = 0; i < len; ++i) { pts[i] = Point::load_affine(&bases[8 * i]); ks[i] = Fr::load(coeffs + 4 * i); }
+    Point acc = host::small_msm(pts, ks);
+    if (w) acc = public_points().S.mul(*w) + acc;
+    *out = acc;
+    return HALO_OK;
+}
+
+// pcdl.rs:99-110
+static int pcdl_commit_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d, const Fr *w, Point *out) {
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_assert("commit: d + 1 is not a power of two");
+    size_t deg = host_poly_degree(coeffs, len);
+    if (deg > d) return fail_assert("commit: p.degree() > d");
+    if (d + 1 > ctx->n) return fail_assert("commit: d > D");
+    size_t used = deg + 1 < len ? deg + 1 : len;
+    if (used <= 16) return commit_short_host(ctx, coeffs, used, w, out);
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    HALO_HIP(hipMemsetAsync(ctx->d_poly2, 0, n * 32, ctx->stream));
+    rc = upload_words(ctx, ctx->d_poly2, coeffs, used * 4);
+    if (rc) return rc;
+    return pedersen_commit_dev(ctx, w, ctx->d_poly2, n, out);
+}
+
+// pcdl.rs:120-242 on a device-resident polynomial (d_poly: n coefficients, zero padded, clobbered)
+static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point &C, size_t d, const Fr &z, const Fr *w,
+                         uint64_t *proof) {
+    size_t n = d + 1, lg_n = ilog2(n);
+    const PublicPoints &pp = public_points();
+    std::memset(proof, 0, 8 * proof_words(lg_n));
+    proof[1] = lg_n;
+    Fr v;
+    int rc = fr_poly_eval(ctx, ctx->d_poly, deg + 1, z, &v);  // :135
+    if (rc) return rc;
+    Point C_prime = C;
+    if (w) {
+        if (deg == 0) return fail_assert("open: hiding needs p.degree() >= 1");  // usize underflow at :141
+        // :140-142  q uniform of degree deg-1, p_bar = q (X - z)
+        rc = rng_scalars_dev(ctx, rng->state, deg, ctx->d_tmp_a);
+        if (rc) return rc;
+        rng->state += 4 * (uint64_t)deg * 0x9E3779B97F4A7C15ULL;
+        HALO_HIP(hipMemsetAsync(ctx->d_poly2, 0, n * 32, ctx->stream));
+        rc = pbar_dev(ctx, ctx->d_tmp_a, deg, z, ctx->d_poly2);
+        if (rc) return rc;
+        Fr w_bar = rng->scalar();  // :147
+        Point C_bar;
+        rc = pedersen_commit_dev(ctx, &w_bar, ctx->d_poly2, n, &C_bar);  // :150
+        if (rc) return rc;
+        Fr a = rho0_C_z_v_Cbar(C, z, v, C_bar);                            // :153
+        rc = axpy_dev(ctx, ctx->d_poly, ctx->d_poly2, deg + 1, a);         // :156
+        if (rc) return rc;
+        Fr w_prime = w_bar * a + *w;                                       // :159
+        C_prime = C + C_bar.mul(a) - pp.S.mul(w_prime);                    // :162
+        proof[0] = 1;
+        C_bar.store_normalized(pf_Cbar(proof, lg_n));
+        w_prime.store(pf_wp(proof, lg_n));
+    } else {
+        Point::infinity().store(pf_Cbar(proof, lg_n));
+    }
+    Fr xi = rho0_C_z_v(C_prime, z, v);  // :180
+    Point Hp = pp.H.mul(xi).normalized();  // :181
+    uint64_t Hp_w[12];
+    Hp.store(Hp_w);
+    halo_ipa *st = nullptr;
+    rc = ipa_begin_dev(ctx, n, ctx->d_poly, z, &st);  // :183-186
+    if (rc) return rc;
+    std::unique_ptr<halo_ipa, void (*)(halo_ipa *)> guard(st, halo_ipa_destroy);
+    for (size_t round = 0; round < lg_n; ++round) {
+        uint64_t *Lw = pf_L(proof, round), *Rw = pf_R(proof, lg_n, round);
+        rc = halo_ipa_round_lr(st, Hp_w, Lw, Rw);  // :203-208
+        if (rc) return rc;
+        Fr xi_next = rho0_xi_L_R(xi, Point::load(Lw), Point::load(Rw));  // :212
+        if (xi_next.is_zero()) return fail_assert("open: challenge is zero (inverse().unwrap())");
+        Fr xi_inv = xi_next.inv();  // :213
+        xi = xi_next;
+        uint64_t xw[4], xiw[4];
+        xi.store(xw);
+        xi_inv.store(xiw);
+        rc = halo_ipa_round_fold(st, xw, xiw);  // :216-224
+        if (rc) return rc;
+    }
+    return halo_ipa_finish(st, pf_U(proof, lg_n), pf_c(proof, lg_n));  // :230-231
+}
+
+// pcdl.rs:252-314.  The 2 lg n + O(1) scalar multiplications are one interleaved host MSM.
+static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c,
+                               std::vector<Fr> *xis_out, Point *U_out) {
+    uint64_t *proof = const_cast<uint64_t *>(proof_c);
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_reject("d+1 is not a power of 2!");
+    if (d + 1 > ctx->n) return fail_reject("d was larger than D!");
+    size_t lg_n = ilog2(n);
+    if (proof[1] != lg_n) return fail_reject("proof length does not match d");
+    const PublicPoints &pp = public_points();
+    Point C_prime = C;
+    if (proof[0]) {
+        Point C_bar = Point::load(pf_Cbar(proof, lg_n));
+        Fr wp = Fr::load(pf_wp(proof, lg_n));
+        Fr a = rho0_C_z_v_Cbar(C, z, v, C_bar);
+        C_prime = C + C_bar.mul(a) - pp.S.mul(wp);
+    }
+    std::vector<Fr> xis(lg_n + 1);
+    xis[0] = rho0_C_z_v(C_prime, z, v);
+    Point Hp = pp.H.mul(xis[0]);
+    std::vector<Point> pts;
+    std::vector<Fr> ks;
+    pts.reserve(2 * lg_n + 1);
+    ks.reserve(2 * lg_n + 1);
+    for (size_t i = 0; i < lg_n; ++i) {
+        Point L = Point::load(pf_L(proof, i)), R = Point::load(pf_R(proof, lg_n, i));
+        xis[i + 1] = rho0_xi_L_R(xis[i], L, R);
+        if (xis[i + 1].is_zero()) return fail_reject("challenge is zero");
+        pts.push_back(L); ks.push_back(xis[i + 1]);  // scalar replaced by its inverse below
+        pts.push_back(R); ks.push_back(xis[i + 1]);
+    }
+    // one inversion for all challenges (Montgomery's trick)
+    {
+        std::vector<Fr> pref(lg_n + 1, Fr::one());
+        for (size_t i = 0; i < lg_n; ++i) pref[i + 1] = pref[i] * xis[i + 1];
+        Fr inv = lg_n ? pref[lg_n].inv() : Fr::one();
+        for (size_t i = lg_n; i-- > 0;) {
+            ks[2 * i] = inv * pref[i];  // xi_{i+1}^-1
+            inv = inv * xis[i + 1];
+        }
+    }
+    pts.push_back(Hp); ks.push_back(v);
+    Point C_i = C_prime + host::small_msm(pts, ks);  // :288-298
+    // :301-304  v' = c * h(z)
+    Fr c = Fr::load(pf_c(proof, lg_n));
+    Fr hz = Fr::one() + xis[lg_n] * z, zi = z;
+    for (size_t i = 1; i < lg_n; ++i) { zi = zi.sqr(); hz = hz * (Fr::one() + xis[lg_n - i] * zi); }
+    Fr v_prime = c * hz;
+    Point U = Point::load(pf_U(proof, lg_n));
+    std::vector<Point> p2{U, Hp};
+    std::vector<Fr> k2{c, v_prime};
+    if (C_i != host::small_msm(p2, k2)) return fail_reject("C_(log_n) != CM.Commit_Sigma(c || v')");  // :307-310
+    *xis_out = std::move(xis);
+    *U_out = U;
+    return HALO_OK;
+}
+
+// pcdl.rs:323-342
+static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof) {
+    std::vector<Fr> xis;
+    Point U;
+    int rc = succinct_check_host(ctx, C, d, z, v, proof, &xis, &U);
+    if (rc) return rc;
+    size_t lg_n = ilog2(d + 1), n = d + 1;
+    rc = h_coeffs_dev(ctx, xis.data(), lg_n, Fr::one(), false, ctx->d_tmp_a);  // h.get_poly().coeffs
+    if (rc) return rc;
+    Point comm;
+    rc = msm_run(ctx, ctx->d_bases, ctx->d_tmp_a, true, n, &comm);  // :338
+    if (rc) return rc;
+    if (U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339
+    return HALO_OK;
+}
+
+// ------------------------------------------------------------------ acc.rs
+struct AccHPolys {  // acc.rs:61-66
+    Fr h0[2];
+    std::vector<std::vector<Fr>> xis;
+    Fr alpha;
+    std::vector<Fr> alphas;  // alpha^0 .. alpha^m
+    size_t lg_n = 0;
+
+    Fr eval(const Fr &z) const {  // acc.rs:97-106
+        Fr v = h0[0] + h0[1] * z;
+        for (size_t i = 0; i < xis.size(); ++i) {
+            const std::vector<Fr> &x = xis[i];
+            Fr hz = Fr::one() + x[lg_n] * z, zi = z;
+            for (size_t k = 1; k < lg_n; ++k) { zi = zi.sqr(); hz = hz * (Fr::one() + x[lg_n - k] * zi); }
+            v = v + hz * alphas[i + 1];
+        }
+        return v;
+    }
+};
+
+// acc.rs:135-188
+static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t m, const Fr h0[2], const Point &U0, const Fr &w,
+                             Point *C_bar_out, Fr *z_out, AccHPolys *hs) {
+    if (!is_pow2(d + 1)) return fail_reject("d+1 is not a power of 2!");
+    size_t lg = ilog2(d + 1), iw = instance_words(lg);
+    hs->h0[0] = h0[0];
+    hs->h0[1] = h0[1];
+    hs->lg_n = lg;
+    std::vector<Point> Us{U0};
+    uint64_t h0w[8];
+    h0[0].store(h0w);
+    h0[1].store(h0w + 4);
+    Point chk;
+    int rc = pcdl_commit_host(ctx, h0w, 2, d, nullptr, &chk);  // :152-155
+    if (rc) return rc;
+    if (U0 != chk) return fail_reject("U_0 != PCDL.Commit(h_0)");
+    for (size_t i = 0; i < m; ++i) {
+        const uint64_t *q = qs + i * iw;
+        std::vector<Fr> xis;
+        Point U;
+        rc = succinct_check_host(ctx, Point::load(q), (size_t)q[12], Fr::load(q + 13), Fr::load(q + 17), q + 21, &xis, &U);  // :164
+        if (rc) return rc;
+        hs->xis.push_back(std::move(xis));
+        Us.push_back(U);
+        if ((size_t)q[12] != d) return fail_reject("d_i != d");  // :169
+    }
+    // :173  alpha = rho_1(hs): h_0 Some(poly), hs Vec<HPoly>, alpha None, alphas empty
+    Transcript t;
+    size_t h0len = h0[1].is_zero() ? (h0[0].is_zero() ? 0 : 1) : 2;
+    t.byte(1); t.u64le(h0len);
+    for (size_t k = 0; k < h0len; ++k) t.scalar(h0[k]);
+    t.u64le(m);
+    for (size_t i = 0; i < m; ++i) { t.u64le(lg + 1); for (size_t k = 0; k <= lg; ++k) t.scalar(hs->xis[i][k]); }
+    t.byte(0); t.u64le(0);
+    hs->alpha = t.finish(1);
+    hs->alphas.assign(m + 1, Fr::one());
+    for (size_t i = 1; i <= m; ++i) hs->alphas[i] = hs->alphas[i - 1] * hs->alpha;
+    Point C = host::small_msm(Us, hs->alphas);  // :178  (m + 1 points)
+    Transcript t2;
+    t2.point(C); t2.scalar(hs->alpha);
+    *z_out = t2.finish(1);                       // :181
+    *C_bar_out = C + public_points().S.mul(w);   // :184
+    return HALO_OK;
+}
+
+}  // namespace halo
+
+using namespace halo;
+
+#define HALO_CTX2(ctx)                                                   \
+    do {                                                                 \
+        if (!(ctx)) { halo::set_error("null context"); return HALO_E_ARG; } \
+        hipError_t _e = hipSetDevice((ctx)->device);                     \
+        if (_e != hipSuccess) return halo::hip_fail(_e, "hipSetDevice"); \
+    } while (0)
+
+extern "C" {
+
+size_t halo_proof_words(size_t lg_n) { return proof_words(lg_n); }
+size_t halo_instance_words(size_t lg_n) { return instance_words(lg_n); }
+size_t halo_accumulator_words(size_t lg_n) { return acc_words(lg_n); }
+
+int halo_pedersen_commit(halo_ctx *ctx, const uint64_t *w, size_t n_bases, const uint64_t *ms, size_t n_ms, uint64_t out[12]) {
+    HALO_CTX2(ctx);
+    if (n_bases != n_ms) return fail_assert("Length did not match for pedersen commitment");  // pedersen.rs:7-12
+    if (n_bases > ctx->n) return fail_assert("pedersen commit: more bases than the key holds");
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    rc = upload_words(ctx, ctx->d_poly2, ms, n_ms * 4);
+    if (rc) return rc;
+    Fr wf = w ? Fr::load(w) : Fr::zero();
+    Point r;
+    rc = pedersen_commit_dev(ctx, w ? &wf : nullptr, ctx->d_poly2, n_ms, &r);
+    if (rc) return rc;
+    r.store_normalized(out);
+    return HALO_OK;
+}
+
+int halo_pcdl_commit(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d, const uint64_t *w, uint64_t out[12]) {
+    HALO_CTX2(ctx);
+    Fr wf = w ? Fr::load(w) : Fr::zero();
+    Point r;
+    int rc = pcdl_commit_host(ctx, coeffs, len, d, w ? &wf : nullptr, &r);
+    if (rc) return rc;
+    r.store_normalized(out);
+    return HALO_OK;
+}
+
+int halo_pcdl_open(halo_ctx *ctx, uint64_t *rng_state, const uint64_t *coeffs, size_t len, const uint64_t C[12], size_t d,
+                   const uint64_t z[4], const uint64_t *w, uint64_t *proof_out) {
+    HALO_CTX2(ctx);
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_assert("open: d + 1 is not a power of two");  // pcdl.rs:130
+    size_t deg = host_poly_degree(coeffs, len);
+    if (deg > d) return fail_assert("open: p.degree() > d");                   // pcdl.rs:131
+    if (n > ctx->n) return fail_assert("open: d > D");                         // pcdl.rs:132
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    HALO_HIP(hipMemsetAsync(ctx->d_poly, 0, n * 32, ctx->stream));
+    rc = upload_words(ctx, ctx->d_poly, coeffs, (deg + 1) * 4);
+    if (rc) return rc;
+    host::Rng rng{rng_state ? *rng_state : 0};
+    Fr wf = w ? Fr::load(w) : Fr::zero();
+    rc = pcdl_open_dev(ctx, &rng, deg, Point::load(C), d, Fr::load(z), w ? &wf : nullptr, proof_out);
+    if (rng_state) *rng_state = rng.state;
+    return rc;
+}
+
+int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
+                             const uint64_t *proof, uint64_t *xis_out, uint64_t U_out[12]) {
+    HALO_CTX2(ctx);
+    std::vector<Fr> xis;
+    Point U;
+    int rc = succinct_check_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof, &xis, &U);
+    if (rc) return rc;
+    for (size_t i = 0; i < xis.size(); ++i) xis[i].store(xis_out + 4 * i);
+    U.store_normalized(U_out);
+    return HALO_OK;
+}
+
+int halo_pcdl_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof) {
+    HALO_CTX2(ctx);
+    return pcdl_check_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof);
+}
+
+// acc.rs:190-220
+int halo_acc_prover(halo_ctx *ctx, uint64_t *rng_state, size_t d, const uint64_t *qs, size_t m, uint64_t *acc) {
+    HALO_CTX2(ctx);
+    if (!is_pow2(d + 1)) return fail_assert("prover: d + 1 is not a power of two");
+    if (d + 1 > ctx->n) return fail_assert("prover: d > D");
+    size_t lg = ilog2(d + 1), n = d + 1;
+    host::Rng rng{rng_state ? *rng_state : 0};
+    Fr h0[2] = {rng.scalar(), rng.scalar()};  // :192
+    uint64_t h0w[8];
+    h0[0].store(h0w);
+    h0[1].store(h0w + 4);
+    Point U0;
+    int rc = pcdl_commit_host(ctx, h0w, 2, d, nullptr, &U0);  // :195
+    if (rc) return rc;
+    Fr w = rng.scalar();  // :198
+    Point C_bar;
+    Fr z;
+    AccHPolys hs;
+    rc = common_subroutine(ctx, d, qs, m, h0, U0, w, &C_bar, &z, &hs);  // :202
+    if (rc) return rc;
+    Fr v = hs.eval(z);  // :205
+    // h.get_poly(): h_0 + sum alpha^(i+1) h_i(X), expanded on the device (acc.rs:85-94)
+    rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    HALO_HIP(hipMemsetAsync(ctx->d_poly, 0, n * 32, ctx->stream));
+    rc = upload_words(ctx, ctx->d_poly, h0w, (n < 2 ? n : 2) * 4);
+    if (rc) return rc;
+    for (size_t i = 0; i < m; ++i) {
+        rc = h_coeffs_dev(ctx, hs.xis[i].data(), lg, hs.alphas[i + 1], true, ctx->d_poly);
+        if (rc) return rc;
+    }
+    std::memset(acc, 0, 8 * acc_words(lg));
+    C_bar = C_bar.normalized();
+    C_bar.store(acc);
+    acc[12] = d;
+    z.store(acc + 13);
+    v.store(acc + 17);
+    size_t deg = m ? d : (h0[1].is_zero() ? 0 : 1);
+    rc = pcdl_open_dev(ctx, &rng, deg, C_bar, d, z, &w, acc + 21);  // :209
+    uint64_t *piV = acc + instance_words(lg);
+    std::memcpy(piV, h0w, 64);
+    U0.store_normalized(piV + 8);
+    w.store(piV + 20);
+    if (rng_state) *rng_state = rng.state;
+    return rc;
+}
+
+// acc.rs:223-243
+int halo_acc_verifier(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t m, const uint64_t *acc) {
+    HALO_CTX2(ctx);
+    if (!is_pow2(d + 1)) return fail_reject("d+1 is not a power of 2!");
+    size_t lg = ilog2(d + 1);
+    const uint64_t *piV = acc + instance_words(lg);
+    Fr h0[2] = {Fr::load(piV), Fr::load(piV + 4)};
+    Point C_bar_p;
+    Fr z_p;
+    AccHPolys hs;
+    int rc = common_subroutine(ctx, d, qs, m, h0, Point::load(piV + 8), Fr::load(piV + 20), &C_bar_p, &z_p, &hs);
+    if (rc) return rc;
+    Fr z = Fr::load(acc + 13), v = Fr::load(acc + 17);
+    if (C_bar_p != Point::load(acc)) return fail_reject("C_bar' != C_bar");
+    if (z_p != z) return fail_reject("z' != z");
+    if ((size_t)acc[12] != d) return fail_reject("d' != d");
+    if (hs.eval(z) != v) return fail_reject("h(z) != v");
+    return HALO_OK;
+}
+
+// acc.rs:245-255
+int halo_acc_decider(halo_ctx *ctx, const uint64_t *acc) {
+    HALO_CTX2(ctx);
+    return pcdl_check_host(ctx, Point::load(acc), (size_t)acc[12], Fr::load(acc + 13), Fr::load(acc + 17), acc + 21);
+}
+
+// benches/acc.rs:15-29 random_instance (workload generator for BASELINE config 4)
+int halo_random_instance(halo_ctx *ctx, uint64_t *rng_state, size_t d, uint64_t *inst) {
+    HALO_CTX2(ctx);
+    if (!is_pow2(d + 1) || d < 2) return fail_assert("random_instance: bad d");
+    if (d + 1 > ctx->n) return fail_assert("random_instance: d > D");
+    size_t lg = ilog2(d + 1), n = d + 1;
+    host::Rng rng{rng_state ? *rng_state : 0};
+    size_t lo = d / 2, d_prime = lo + (size_t)(rng.next() % (uint64_t)(d - lo));
+    if (d_prime == 0) d_prime = 1;
+    Fr w = rng.scalar();
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    // p = PallasPoly::rand(d_prime): d_prime + 1 scalars of the stream, generated on the device
+    HALO_HIP(hipMemsetAsync(ctx->d_poly, 0, n * 32, ctx->stream));
+    rc = rng_scalars_dev(ctx, rng.state, d_prime + 1, ctx->d_poly);
+    if (rc) return rc;
+    rng.state += 4 * (uint64_t)(d_prime + 1) * 0x9E3779B97F4A7C15ULL;
+    Point C;
+    rc = pedersen_commit_dev(ctx, &w, ctx->d_poly, n, &C);
+    if (rc) return rc;
+    C = C.normalized();
+    Fr z = rng.scalar(), v;
+    rc = fr_poly_eval(ctx, ctx->d_poly, d_prime + 1, z, &v);
+    if (rc) return rc;
+    std::memset(inst, 0, 8 * instance_words(lg));
+    C.store(inst);
+    inst[12] = d;
+    z.store(inst + 13);
+    v.store(inst + 17);
+    // the leading coefficient is non-zero with overwhelming probability: degree = d_prime
+    rc = pcdl_open_dev(ctx, &rng, d_prime, C, d, z, &w, inst + 21);
+    if (rng_state) *rng_state = rng.state;
+    return rc;
+}
+
+}  // extern "C"

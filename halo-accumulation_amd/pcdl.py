@@ -1,0 +1,65 @@
+"""Mirror of the reference's `pcdl` module (code/src/pcdl.rs): commit / open / succinct_check / check.
+
+Polynomials are coefficient arrays (len, 4); proofs are the flat EvalProof blobs described in
+include/halo_accumulation.h.  `rng` is a one-element list holding a SplitMix64 state (mutated),
+standing in for the reference's `rng: &mut R`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from halo_accumulation_amd import _lib
+from halo_accumulation_amd._lib import check, ptr
+
+
+def _a(x):
+    return None if x is None else np.ascontiguousarray(x, dtype=np.uint64)
+
+
+def lg_of(d):
+    return (d + 1).bit_length() - 1
+
+
+def commit(ctx, p, d, w=None):
+    """pcdl.rs:99-110"""
+    p = _a(p).reshape(-1, 4)
+    out = np.zeros(12, dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_commit(ctx.h, ptr(p), p.shape[0], d, ptr(_a(w)), ptr(out)))
+    return out
+
+
+def open(ctx, rng, p, Cm, d, z, w=None):
+    """pcdl.rs:120-242 -> EvalProof blob"""
+    p = _a(p).reshape(-1, 4)
+    st = C.c_uint64(rng[0])
+    proof = np.zeros(ctx.lib.halo_proof_words(max(lg_of(d), 0)), dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_open(ctx.h, C.byref(st), ptr(p), p.shape[0], ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(w)), ptr(proof)))
+    rng[0] = st.value
+    return proof
+
+
+def succinct_check(ctx, Cm, d, z, v, pi):
+    """pcdl.rs:252-314 -> (xis of h, U); raises HaloReject where the reference returns Err"""
+    lg = max(lg_of(d), 0)
+    xis = np.zeros((lg + 1, 4), dtype=np.uint64)
+    U = np.zeros(12, dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_succinct_check(ctx.h, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(v)), ptr(_a(pi)), ptr(xis), ptr(U)))
+    return xis, U
+
+
+def check_proof(ctx, Cm, d, z, v, pi):
+    """pcdl::check (pcdl.rs:323-342)"""
+    check(ctx.lib.halo_pcdl_check(ctx.h, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(v)), ptr(_a(pi))))
+
+
+class HPoly:
+    """pcdl.rs:44-92"""
+
+    def __init__(self, ctx, xis):
+        self.ctx, self.xis = ctx, _a(xis).reshape(-1, 4)
+
+    def get_poly(self):
+        return self.ctx.h_coeffs(self.xis)
+
+    def eval(self, z):
+        return self.ctx.h_eval_batch(self.xis[None], z)[0]

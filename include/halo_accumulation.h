@@ -99,6 +99,37 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]);
 void halo_ipa_destroy(halo_ipa *st);
 size_t halo_ipa_len(const halo_ipa *st);
 
+/* ---- pcdl / acc level: the reference's public functions, host glue in C++, linear work in HIP
+ *
+ * Flat layouts (u64 words), lg = log2(d + 1):
+ *   EvalProof (pcdl.rs:22-30): [0] hiding flag | [1] lg | Ls lg*12 | Rs lg*12 | U 12 | c 4 | C_bar 12 | w' 4
+ *   Instance  (acc.rs:21-28) : C 12 | d 1 | z 4 | v 4 | EvalProof
+ *   Accumulator (acc.rs:43-59): Instance fields (C_bar, d, z, v, pi) | h0 8 (two Fr) | U0 12 | w 4
+ * `rng_state` is a SplitMix64 state (the reference takes `rng: &mut R`): scalars are 4 draws,
+ * little-endian, reduced mod r; the state is advanced exactly as a sequential stream would be. */
+size_t halo_proof_words(size_t lg_n);
+size_t halo_instance_words(size_t lg_n);
+size_t halo_accumulator_words(size_t lg_n);
+/* pedersen::commit (pedersen.rs:6-20) over GS[0..n_bases) */
+int halo_pedersen_commit(halo_ctx *ctx, const uint64_t *w /*nullable*/, size_t n_bases, const uint64_t *ms, size_t n_ms,
+                         uint64_t out[12]);
+/* pcdl::commit (pcdl.rs:99-110) */
+int halo_pcdl_commit(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d, const uint64_t *w /*nullable*/, uint64_t out[12]);
+/* pcdl::open (pcdl.rs:120-242) */
+int halo_pcdl_open(halo_ctx *ctx, uint64_t *rng_state, const uint64_t *coeffs, size_t len, const uint64_t C[12], size_t d,
+                   const uint64_t z[4], const uint64_t *w /*nullable*/, uint64_t *proof_out);
+/* pcdl::succinct_check (pcdl.rs:252-314): xis_out (lg+1) x 4, U_out */
+int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
+                             const uint64_t *proof, uint64_t *xis_out, uint64_t U_out[12]);
+/* pcdl::check (pcdl.rs:323-342) */
+int halo_pcdl_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof);
+/* acc::prover / verifier / decider (acc.rs:190-255); instances = m contiguous Instance blobs */
+int halo_acc_prover(halo_ctx *ctx, uint64_t *rng_state, size_t d, const uint64_t *instances, size_t m, uint64_t *acc_out);
+int halo_acc_verifier(halo_ctx *ctx, size_t d, const uint64_t *instances, size_t m, const uint64_t *acc);
+int halo_acc_decider(halo_ctx *ctx, const uint64_t *acc);
+/* benches/acc.rs:15-29 random_instance: the workload generator of the reference's benchmark */
+int halo_random_instance(halo_ctx *ctx, uint64_t *rng_state, size_t d, uint64_t *instance_out);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */
 /* When enabled, every kernel launch on this ctx is bracketed by hipEvents on the ctx stream. */
 int halo_prof_enable(halo_ctx *ctx, int on);

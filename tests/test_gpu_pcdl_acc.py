@@ -1,0 +1,217 @@
+"""GPU parity for the kernels behind pcdl::open / check and the acc scheme, written after the
+reference's own unit tests (pcdl.rs:352-509, acc.rs:299-315, pedersen.rs:30-63), plus
+blob-for-blob equality with the CPU restatement on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import orc
+import pallas_model as pm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hal():
+    import halo_accumulation_amd as h
+    return h
+
+
+@pytest.fixture(scope="module")
+def ctx(hal):
+    c = hal._lib.Context(urs_n=4096)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def pp(ctx):
+    gs = ctx.read_bases()
+    return orc.make_pp(gs)
+
+
+def canon(j):
+    return orc.point_canonical(j)
+
+
+# ------------------------------------------------------------------ Fr kernels (K4-K9)
+@pytest.mark.parametrize("m", [1, 2, 63, 64, 65, 1000, 4096])
+def test_scalar_dot_powers_poly_eval(ctx, m):
+    xs, s = orc.rng_scalars(m, m)
+    ys, s = orc.rng_scalars(s, m)
+    z, _ = orc.rng_scalars(s, 1)
+    assert ctx.scalar_dot(xs, ys).tolist() == orc.scalar_dot(xs, ys).tolist()
+    assert ctx.powers(z[0], m).tolist() == orc.powers(z[0], m).tolist()
+    assert ctx.poly_eval(xs, z[0]).tolist() == orc.poly_eval(xs, z[0]).tolist()
+
+
+@pytest.mark.parametrize("lg_n", [1, 2, 3, 7, 8, 9, 12])
+def test_h_coeffs_eval_commit(ctx, lg_n):
+    """pcdl.rs:486-509 ordering, pcdl.rs:352-379 eval, pcdl.rs:338 commit."""
+    xis, s = orc.rng_scalars(100 + lg_n, lg_n + 1)
+    z, _ = orc.rng_scalars(s, 1)
+    want = orc.h_coeffs(xis)
+    assert ctx.h_coeffs(xis).tolist() == want.tolist()
+    assert ctx.h_eval_batch(xis[None], z[0])[0].tolist() == orc.h_eval(xis, z[0]).tolist()
+    gs = ctx.read_bases(0, 1 << lg_n)
+    assert ctx.h_commit(xis).tolist() == orc.msm_affine(gs, want).tolist()
+
+
+def test_h_eval_batch_and_accumulate(ctx):
+    lg_n, m = 10, 37
+    flat, s = orc.rng_scalars(5, m * (lg_n + 1))
+    xis = flat.reshape(m, lg_n + 1, 4)
+    z, s = orc.rng_scalars(s, 1)
+    got = ctx.h_eval_batch(xis.reshape(m, -1), z[0])
+    for i in range(m):
+        assert got[i].tolist() == orc.h_eval(np.ascontiguousarray(xis[i]), z[0]).tolist()
+    # acc.rs:85-94: h0 + sum alpha_i h_i
+    al, s = orc.rng_scalars(s, 3)
+    h0, _ = orc.rng_scalars(s, 2)
+    got = ctx.h_accumulate(h0, xis[:3].reshape(3, -1), al)
+    want = [0] * (1 << lg_n)
+    want[0], want[1] = orc.fr_from_mont(h0[0]), orc.fr_from_mont(h0[1])
+    for i in range(3):
+        a = orc.fr_from_mont(al[i])
+        hc = orc.h_coeffs(np.ascontiguousarray(xis[i]))
+        for k in range(1 << lg_n):
+            want[k] = (want[k] + a * orc.fr_from_mont(hc[k])) % pm.R_ORDER
+    assert [orc.fr_from_mont(g) for g in got] == want
+
+
+def test_u_check(hal, ctx):
+    """pcdl.rs:382-438 with xi = [0,1,2,3]: device fold of G == MSM(GS, h_coeffs) == SURVEY anchor."""
+    xm = orc.scalars_to_mont([0, 1, 2, 3])
+    zero = np.zeros((8, 4), dtype=np.uint64)
+    one = orc.fr_to_mont(1)
+    ipa = hal._lib.Ipa(ctx, 8, zero, one)
+    for i in range(3):
+        ipa.round_fold(xm[i + 1], one)
+    U, c = ipa.finish()
+    want = ("18cef7a91c998eab6266eaa5c7523a520b6f9b56aefe02b7cb48b226b9c0530c",
+            "2cc9cee89d461087f1312759efb678ec548f5cda04f99a56429ae889cc2d7da3")
+    assert tuple("%064x" % v for v in canon(U)) == want
+    assert tuple("%064x" % v for v in canon(ctx.h_commit(xm))) == want
+    assert [orc.fr_from_mont(c) for c in ctx.h_coeffs(xm)] == [1, 3, 2, 6, 1, 3, 2, 6]
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 1024])
+def test_ipa_rounds_vs_oracle(hal, ctx, pp, n):
+    """Kernel-level parity of pcdl.rs:195-227: L, R and the folded state, round by round."""
+    gs = ctx.read_bases(0, n)
+    coeffs, s = orc.rng_scalars(n, n - 1 if n > 2 else n)
+    zx, s = orc.rng_scalars(s, 2)
+    z = zx[0]
+    Hp = np.array(pp.H, dtype=np.uint64)
+    ipa = hal._lib.Ipa(ctx, n, coeffs, z)
+    gj = np.zeros((n, 12), dtype=np.uint64)
+    for i in range(n):
+        orc.lib().orc_affine_to_jac(orc.ptr(gs[i]), orc.ptr(gj[i]))
+    cs = np.zeros((n, 4), dtype=np.uint64); cs[: len(coeffs)] = coeffs
+    zs = orc.powers(z, n)
+    m = n // 2
+    seed = s
+    while m >= 1:
+        L, R = ipa.round_lr(Hp)
+        Lw, Rw = orc.z(12), orc.z(12)
+        orc.lib().orc_ipa_round_lr(orc.ptr(gj), orc.ptr(cs), orc.ptr(zs), orc.C.c_size_t(m), orc.ptr(Hp), orc.ptr(Lw), orc.ptr(Rw))
+        assert L.tolist() == Lw.tolist() and R.tolist() == Rw.tolist()
+        xi, seed = orc.rng_scalars(seed, 1)
+        xi_inv = orc.z(4); assert orc.lib().orc_fr_inv(orc.ptr(xi[0]), orc.ptr(xi_inv)) == 0
+        ipa.round_fold(xi[0], xi_inv)
+        orc.lib().orc_ipa_round_fold(orc.ptr(gj), orc.ptr(cs), orc.ptr(zs), orc.C.c_size_t(m), orc.ptr(xi[0]), orc.ptr(xi_inv))
+        m //= 2
+    U, c = ipa.finish()
+    assert canon(U) == canon(gj[0]) and c.tolist() == cs[0].tolist()
+
+
+# ------------------------------------------------------------------ pcdl level
+def test_pedersen_homomorphism(hal, ctx):
+    """pedersen.rs:30-63"""
+    from halo_accumulation_amd import pedersen
+    l = 64
+    m1, s = orc.rng_scalars(11, l)
+    m2, s = orc.rng_scalars(s, l)
+    ws, _ = orc.rng_scalars(s, 2)
+    msum = ctx.field_op(1, 1, m1, m2)
+    wsum = ctx.field_op(1, 1, ws[:1], ws[1:2])[0]
+    inner = pedersen.commit(ctx, wsum, l, msum)
+    o = orc.z(12)
+    orc.lib().orc_point_add(orc.ptr(pedersen.commit(ctx, ws[0], l, m1)), orc.ptr(pedersen.commit(ctx, ws[1], l, m2)), orc.ptr(o))
+    assert inner.tolist() == o.tolist()
+    with pytest.raises(AssertionError):
+        pedersen.commit(ctx, None, l, m1[:-1])
+
+
+@pytest.mark.parametrize("n,hiding", [(4, False), (4, True), (16, True), (512, False), (512, True), (4096, True)])
+def test_open_check_matches_oracle(hal, ctx, pp, n, hiding):
+    """pcdl.rs:441-483 completeness, and proof blobs identical to the CPU restatement's."""
+    from halo_accumulation_amd import pcdl
+    d = n - 1
+    deg = max(1, d - 2) if n <= 16 else n // 2 + 3
+    coeffs, s = orc.rng_scalars(0x48414C4F00000003 + n, deg + 1)
+    zw, s = orc.rng_scalars(s, 2)
+    z, w = zw[0], (zw[1] if hiding else None)
+    C = pcdl.commit(ctx, coeffs, d, w)
+    assert C.tolist() == orc.pcdl_commit(pp, coeffs, d, w).tolist()
+    rng = [4242 + n]
+    pi = pcdl.open(ctx, rng, coeffs, C, d, z, w)
+    pi_ref, st_ref = orc.pcdl_open(pp, 4242 + n, coeffs, C, d, z, w)
+    assert pi.tolist() == pi_ref.tolist()
+    assert rng[0] == st_ref
+    v = ctx.poly_eval(coeffs, z)
+    pcdl.check_proof(ctx, C, d, z, v, pi)
+    orc.pcdl_check(pp, C, d, z, v, pi)
+    xis, U = pcdl.succinct_check(ctx, C, d, z, v, pi)
+    xis_ref, U_ref = orc.pcdl_succinct_check(pp, C, d, z, v, pi)
+    assert xis.tolist() == xis_ref.tolist() and U.tolist() == U_ref.tolist()
+    bad_v = orc.fr_to_mont((orc.fr_from_mont(v) + 1) % pm.R_ORDER)
+    with pytest.raises(ValueError):
+        pcdl.check_proof(ctx, C, d, z, bad_v, pi)
+    bad = pi.copy(); bad[2 + 24 * (n.bit_length() - 1) + 12] ^= 1  # c
+    with pytest.raises(ValueError):
+        pcdl.succinct_check(ctx, C, d, z, v, bad)
+    # a proof whose U is not the commitment to h passes the succinct check only if C matches: flip U and c consistently is
+    # infeasible, so just check that check() rejects a wrong U
+    bad = pi.copy(); bad[2 + 24 * (n.bit_length() - 1): 2 + 24 * (n.bit_length() - 1) + 12] = C
+    with pytest.raises(ValueError):
+        pcdl.check_proof(ctx, C, d, z, v, bad)
+
+
+def test_commit_open_asserts(hal, ctx):
+    from halo_accumulation_amd import pcdl
+    coeffs, _ = orc.rng_scalars(5, 8)
+    with pytest.raises(AssertionError):
+        pcdl.commit(ctx, coeffs, 6)          # pcdl.rs:102
+    with pytest.raises(AssertionError):
+        pcdl.commit(ctx, coeffs, 3)          # pcdl.rs:103
+    with pytest.raises(AssertionError):
+        pcdl.commit(ctx, coeffs, 8191)       # pcdl.rs:104 (D = 4095 here)
+    C = pcdl.commit(ctx, coeffs, 7)
+    with pytest.raises(AssertionError):
+        pcdl.open(ctx, [1], coeffs, C, 6, coeffs[0])   # pcdl.rs:130
+
+
+# ------------------------------------------------------------------ acc level
+@pytest.mark.parametrize("n,steps", [(4, 3), (16, 3), (1024, 2)])
+def test_acc_scheme_matches_oracle(hal, ctx, pp, n, steps):
+    """acc.rs:299-315: chained prover + verifier, then decider; accumulators equal the oracle's."""
+    from halo_accumulation_amd import acc as A
+    d = n - 1
+    rng = [1000 + n]
+    seed = 1000 + n
+    acc = acc_ref = None
+    for _ in range(steps):
+        q = A.random_instance(ctx, rng, d)
+        q_ref, seed = orc.random_instance(pp, seed, d)
+        assert q.tolist() == q_ref.tolist() and rng[0] == seed
+        qs = [q] if acc is None else [A.instance_from_accumulator(ctx, acc, d), q]
+        acc = A.prover(ctx, rng, d, qs)
+        acc_ref, seed = orc.acc_prover(pp, seed, d, qs)
+        assert acc.tolist() == acc_ref.tolist() and rng[0] == seed
+        A.verifier(ctx, d, qs, acc)
+        orc.acc_verifier(pp, d, qs, acc)
+        bad = acc.copy(); bad[17] ^= 1
+        with pytest.raises(ValueError):
+            A.verifier(ctx, d, qs, bad)
+    A.decider(ctx, acc)
+    orc.acc_decider(pp, acc)

@@ -1,0 +1,28 @@
+"""Per-kernel timing of pcdl::open + check on the GPU box (development aid)."""
+import sys, time, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import halo_accumulation_amd as h
+from halo_accumulation_amd import pcdl
+import orc
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+hiding = len(sys.argv) > 2 and sys.argv[2] == "hiding"
+n = 1 << lg; d = n - 1
+t = time.time(); ctx = h._lib.Context(urs_n=n); print("ctx urs %d: %.2fs" % (n, time.time() - t), flush=True)
+coeffs, s = orc.rng_scalars(3, n)
+zw, _ = orc.rng_scalars(s, 2)
+z, w = zw[0], (zw[1] if hiding else None)
+t = time.time(); C = pcdl.commit(ctx, coeffs, d, w); print("commit %.2f ms" % ((time.time() - t) * 1e3))
+pi = pcdl.open(ctx, [7], coeffs, C, d, z, w)  # warm-up
+ctx.prof_enable(True); ctx.prof_reset()
+t = time.time(); pi = pcdl.open(ctx, [7], coeffs, C, d, z, w); t_open = time.time() - t
+print("open (profiled) %.2f ms" % (t_open * 1e3))
+for k, (ms, cnt) in sorted(ctx.prof().items(), key=lambda kv: -kv[1][0]):
+    print("   %-22s total %9.3f ms  launches %4d  avg %8.3f ms" % (k, ms, cnt, ms / max(cnt, 1)))
+ctx.prof_enable(False)
+t = time.time(); pi = pcdl.open(ctx, [7], coeffs, C, d, z, w); print("open (unprofiled) %.2f ms" % ((time.time() - t) * 1e3))
+v = ctx.poly_eval(coeffs, z)
+t = time.time(); pcdl.succinct_check(ctx, C, d, z, v, pi); print("succinct_check %.2f ms" % ((time.time() - t) * 1e3))
+t = time.time(); pcdl.check_proof(ctx, C, d, z, v, pi); print("check %.2f ms" % ((time.time() - t) * 1e3), flush=True)
