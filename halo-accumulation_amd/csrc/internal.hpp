@@ -61,11 +61,12 @@ struct MsmWorkspace {
     uint32_t *d_blockoff = nullptr;  // per 4096-entry block offset
     uint32_t *d_cursor = nullptr;    // W*B
     uint32_t *d_sorted = nullptr;    // n*W entries: point index | sign << 31
-    uint64_t *d_buckets = nullptr;   // W*B x 16 (XYZZ)
+    uint64_t *d_buckets = nullptr;   // one XYZZ partial (16 words) per task
+    uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
     uint64_t *d_seg = nullptr;       // W*64 x 2 x 16 (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
-    size_t cap_counts = 0, cap_sorted = 0;
+    size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0;
 };
 
 }  // namespace halo

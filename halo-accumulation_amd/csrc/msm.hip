@@ -133,14 +133,51 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *blocksum, uint32_t 
 }
 
 // ------------------------------------------------------------------------------ accumulate
+// Buckets are cut into tasks of at most KMAX entries so that no lane ever runs a chain longer
+// than KMAX mixed adds, whatever the scalar distribution (all-equal scalars, or a top window
+// with two real bits, put n/4 .. n points into one bucket).  ntask[g] = ceil(count/KMAX);
+// toff = exclusive scan of ntask.  One lane per task; a bucket's value is the partial of its
+// first task once k_msm_combine_big has folded the partials of multi-task buckets into it.
+constexpr uint32_t KMAX = 64;
+
+__global__ __launch_bounds__(256) void k_msm_ntasks(const uint32_t *__restrict__ counts, uint32_t total, uint32_t *__restrict__ ntask) {
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    ntask[g] = (counts[g] + KMAX - 1) / KMAX;
+}
+
+HALO_DEV uint32_t scan_at(const uint32_t *__restrict__ in_block, const uint32_t *__restrict__ blockoff, uint32_t g) {
+    return in_block[g] + blockoff[g >> 12];
+}
+
+// meta[0] = number of tasks, meta[1] = number of multi-task buckets (biglist length)
+__global__ __launch_bounds__(256) void k_msm_task_meta(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                                                       const uint32_t *__restrict__ tblockoff, uint32_t total, uint32_t *__restrict__ meta,
+                                                       uint32_t *__restrict__ biglist) {
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    if (g == total - 1) meta[0] = scan_at(toff, tblockoff, g) + ntask[g];
+    if (ntask[g] > 1) biglist[atomicAdd(&meta[1], 1u)] = g;
+}
+
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
-                                                        const uint32_t *__restrict__ counts, uint32_t total_buckets,
-                                                        uint64_t *__restrict__ buckets) {
-    uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= total_buckets) return;
-    uint32_t cnt = counts[g];
-    uint32_t st = starts[g] + blockoff[g >> 12];
+                                                        const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
+                                                        const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
+                                                        uint32_t total_buckets, uint64_t *__restrict__ partial) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= meta[0]) return;
+    // bucket of task t: last g with toff(g) <= t (ties are empty buckets, which sort before their non-empty successor)
+    uint32_t lo = 0, hi = total_buckets - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (scan_at(toff, tblockoff, mid) <= t) lo = mid; else hi = mid - 1;
+    }
+    uint32_t g = lo;
+    uint32_t first = (t - scan_at(toff, tblockoff, g)) * KMAX;
+    uint32_t cnt = counts[g] - first;
+    if (cnt > KMAX) cnt = KMAX;
+    uint32_t st = scan_at(starts, blockoff, g) + first;
     Xyzz acc = xyzz_inf();
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t e = sorted[st + k];
@@ -148,7 +185,37 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint64_t *__restri
         p = aff_cneg(p, (e >> 31) != 0);
         xyzz_madd(acc, p);
     }
-    xyzz_store(buckets + 16 * (size_t)g, acc);
+    xyzz_store(partial + 16 * (size_t)t, acc);
+}
+
+// one wave per multi-task bucket (grid-stride over biglist): partial[toff(g)] <- sum of its partials
+__global__ __launch_bounds__(64) void k_msm_combine_big(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                                                        const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
+                                                        const uint32_t *__restrict__ biglist, uint64_t *__restrict__ partial) {
+    uint32_t lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < meta[1]; b += gridDim.x) {
+        uint32_t g = biglist[b];
+        uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
+        Xyzz acc = xyzz_inf();
+#pragma unroll 1
+        for (uint32_t j = lane; j < nt; j += 64) {
+            Xyzz q = xyzz_load(partial + 16 * (size_t)(t0 + j));
+            xyzz_add(acc, q);
+        }
+#pragma unroll 1
+        for (int off = 32; off >= 1; off >>= 1) {
+            Xyzz o = xyzz_shfl(acc, (lane + off) & 63);
+            if ((int)lane < off) xyzz_add(acc, o);
+        }
+        if (lane == 0) xyzz_store(partial + 16 * (size_t)t0, acc);
+    }
+}
+
+// value of bucket g after the combine pass
+HALO_DEV Xyzz bucket_value(const uint64_t *__restrict__ partial, const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                           const uint32_t *__restrict__ tblockoff, uint32_t g) {
+    if (ntask[g] == 0) return xyzz_inf();
+    return xyzz_load(partial + 16 * (size_t)scan_at(toff, tblockoff, g));
 }
 
 // ------------------------------------------------------------------------------ reduce
@@ -175,8 +242,9 @@ HALO_DEV void wave_weighted_sum(Xyzz &S, Xyzz &T, int k) {
 }
 
 // one wave per (window, segment of 64*L buckets)
-__global__ __launch_bounds__(64) void k_msm_reduce1(const uint64_t *__restrict__ buckets, uint32_t B, uint32_t L, int logL,
-                                                    uint32_t nseg, uint64_t *__restrict__ seg) {
+__global__ __launch_bounds__(64) void k_msm_reduce1(const uint64_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
+                                                    const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff, uint32_t B,
+                                                    uint32_t L, int logL, uint32_t nseg, uint64_t *__restrict__ seg) {
     uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
     uint32_t lane = threadIdx.x;
     uint32_t first = s * 64 * L + lane * L;
@@ -185,7 +253,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint64_t *__restrict__
     for (int j = (int)L - 1; j >= 0; j--) {
         uint32_t idx = first + (uint32_t)j;
         Xyzz b = xyzz_inf();
-        if (idx < B) b = xyzz_load(buckets + 16 * ((size_t)w * B + idx));
+        if (idx < B) b = bucket_value(partial, ntask, toff, tblockoff, w * B + idx);
         xyzz_add(run, b);
         xyzz_add(tot, run);
     }
@@ -360,8 +428,8 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out)
     HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, d_tbl, reinterpret_cast<const uint32_t *>(d_canon), (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(d_tbl);
-    hipFree(d_canon);
+    (void)hipFree(d_tbl);
+    (void)hipFree(d_canon);
     return HALO_OK;
 }
 
@@ -372,26 +440,8 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     MsmWorkspace &ws = ctx->ws;
     if (n < 64) n = 64;
     ws.cap_n = n;
-    size_t cnt = 0, srt = 0;
-    for (size_t m = 1; m <= n; m <<= 1) {
-        for (int c = 4; c <= 16; ++c) {
-            MsmPlan p = msm_plan(m, c);
-            if (ctx->window_bits == 0 && c != msm_plan(m, 0).c && c != 16) continue;
-            size_t tb = (size_t)p.W * p.B;
-            if (tb > cnt) cnt = tb;
-        }
-    }
-    if (cnt > max_counts()) cnt = max_counts();
-    srt = n * 64;  // W <= 64
-    // tighter: for the automatic plan W shrinks as n grows; keep n*W of the worst automatic plan
-    size_t worst = 0;
-    for (size_t m = 1; m <= n; m <<= 1) {
-        size_t mm = m * 2 - 1 < n ? m * 2 - 1 : n;
-        MsmPlan p = msm_plan(m, 0);
-        if (mm * p.W > worst) worst = mm * (size_t)p.W;
-    }
-    if (worst < srt) srt = worst;
-    if (srt < n * 22) srt = n * 22;  // room for forced c >= 12
+    // sorted entries: n * W; the automatic plan has W <= 32 for n >= 4096 (c >= 8) and W <= 64 below
+    size_t srt = n >= 4096 ? n * 32 : n * 64;
     ws.cap_counts = max_counts();
     ws.cap_sorted = srt;
     HALO_HIP(hipMalloc(&ws.d_canon, n * 32));
@@ -400,7 +450,14 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     HALO_HIP(hipMalloc(&ws.d_cursor, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
-    HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_counts * 128));
+    // tasks <= non-empty buckets + entries / KMAX
+    ws.cap_tasks = ws.cap_counts + ws.cap_sorted / KMAX + 1;
+    HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * 128));
+    HALO_HIP(hipMalloc(&ws.d_ntask, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_tblockoff, 1024 * 4));
+    HALO_HIP(hipMalloc(&ws.d_biglist, ws.cap_counts * 4));
+    HALO_HIP(hipMalloc(&ws.d_meta, 64));
     HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 32 * 8));
     HALO_HIP(hipMalloc(&ws.d_winsum, (size_t)64 * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, (size_t)64 * 12 * 8));
@@ -408,9 +465,11 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
 }
 void msm_workspace_free(halo_ctx *ctx) {
     MsmWorkspace &ws = ctx->ws;
-    hipFree(ws.d_canon); hipFree(ws.d_counts); hipFree(ws.d_starts); hipFree(ws.d_cursor); hipFree(ws.d_blockoff);
-    hipFree(ws.d_sorted); hipFree(ws.d_buckets); hipFree(ws.d_seg); hipFree(ws.d_winsum);
-    if (ws.h_winsum) hipHostFree(ws.h_winsum);
+    uint64_t *p64[] = {ws.d_canon, ws.d_buckets, ws.d_seg, ws.d_winsum};
+    uint32_t *p32[] = {ws.d_counts, ws.d_starts, ws.d_cursor, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta};
+    for (auto p : p64) (void)hipFree(p);
+    for (auto p : p32) (void)hipFree(p);
+    if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
     ws = MsmWorkspace();
 }
 
@@ -434,14 +493,26 @@ int msm_run(halo_ctx *ctx, const uint64_t *d_bases, const uint64_t *d_scalars, b
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
     HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridn, b256, 0, ws.d_canon, (uint32_t)n, p.c, p.W, p.B, ws.d_starts, ws.d_blockoff,
                 ws.d_cursor, ws.d_sorted);
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, dim3((unsigned)((total + 255) / 256)), b256, 0, d_bases, ws.d_sorted,
-                ws.d_starts, ws.d_blockoff, ws.d_counts, (uint32_t)total, ws.d_buckets);
+    dim3 gridb((unsigned)((total + 255) / 256));
+    HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 64, s));
+    HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, ws.d_ntask);
+    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
+    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
+    HALO_LAUNCH(ctx, "k_msm_task_meta", k_msm_task_meta, gridb, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, (uint32_t)total, ws.d_meta,
+                ws.d_biglist);
+    size_t max_tasks = total + n * (size_t)p.W / KMAX + 1;
+    if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, dim3((unsigned)((max_tasks + 255) / 256)), b256, 0, d_bases, ws.d_sorted,
+                ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff, ws.d_tblockoff, ws.d_meta, (uint32_t)total, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_combine_big", k_msm_combine_big, dim3(1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
+                ws.d_biglist, ws.d_buckets);
     uint32_t L, nseg;
     int logL = 0;
     if (p.B <= 512) { nseg = 1; L = p.B >= 64 ? p.B / 64 : 1; }
     else { L = 8; nseg = p.B / 512; }
     while ((1u << logL) < L) logL++;
-    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, p.B, L, logL, nseg, ws.d_seg);
+    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
+                ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
     HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)p.W), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)p.W * 96, hipMemcpyDeviceToHost, s));

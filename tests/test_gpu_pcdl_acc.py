@@ -61,13 +61,13 @@ def test_h_eval_batch_and_accumulate(ctx):
     flat, s = orc.rng_scalars(5, m * (lg_n + 1))
     xis = flat.reshape(m, lg_n + 1, 4)
     z, s = orc.rng_scalars(s, 1)
-    got = ctx.h_eval_batch(xis.reshape(m, -1), z[0])
+    got = ctx.h_eval_batch(xis, z[0])
     for i in range(m):
         assert got[i].tolist() == orc.h_eval(np.ascontiguousarray(xis[i]), z[0]).tolist()
     # acc.rs:85-94: h0 + sum alpha_i h_i
     al, s = orc.rng_scalars(s, 3)
     h0, _ = orc.rng_scalars(s, 2)
-    got = ctx.h_accumulate(h0, xis[:3].reshape(3, -1), al)
+    got = ctx.h_accumulate(h0, xis[:3], al)
     want = [0] * (1 << lg_n)
     want[0], want[1] = orc.fr_from_mont(h0[0]), orc.fr_from_mont(h0[1])
     for i in range(3):
