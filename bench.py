@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Pippenger MSMs/sec at n = 2^20 (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--open-steps J]
+
+A step = one MSM over n random scalars (resident in HBM) and the URS bases G_0..G_{n-1}
+(derived on the GPU by the reference's main.rs rule).  N > 1 (launched by torch.distributed.run,
+one rank per GPU): the SAME n-point MSM is index-sharded, each rank reduces its block to one
+point and the partials are all-gathered over RCCL and summed (strong scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--open-steps", type=int, default=2, help="PCDL open+check repetitions at N=1 (0 = skip)")
+    ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd import pcdl
+    from halo_accumulation_amd.sharded import ShardedMsm, shard_range
+    import orc
+
+    n = 1 << args.log_n
+    lo, hi = shard_range(n, rank, world)
+    # this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
+    ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=local_rank)
+    sc_all, _ = orc.rng_scalars(0x48414C4F00000002, n)  # BASELINE.md section 2, seed ...02
+    d_sc = torch.from_numpy(sc_all[lo:hi].view(np.int64).copy()).to(dev)
+    msm = ShardedMsm(lambda: ctx.msm_dev(d_sc.data_ptr(), hi - lo), h._lib.point_sum, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = msm()
+    ctx.prof_enable(2)  # HIP events around the dominant kernel only, on the ctx stream
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = msm()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    prof = ctx.prof()
+    ctx.prof_enable(0)
+
+    result = None
+    if rank == 0:
+        acc_ms, acc_cnt = prof.get("k_msm_accumulate", (0.0, 0))
+        kern_s = acc_ms / max(acc_cnt, 1) * 1e-3
+        alg_bytes = 96 * (hi - lo) + 64  # 64 B base + 32 B scalar per point, one point out
+        achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+        result = {
+            "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
+            "value": args.steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
+            "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
+                       "sharding": "block index shard per rank + RCCL all-gather of 96 B partials" if world > 1 else "single GPU",
+                       "window_bits": "auto (c = floor(log2 n) - 4, clamped to [4,16])"},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes": alg_bytes,
+                         "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
+            "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
+        }
+
+    if world == 1:
+        # bit-exactness in the same run + CPU baseline (oracle = single-thread port of the arkworks path)
+        gs = ctx.read_bases()
+        if args.cpu_msms > 0:
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_msms):
+                want = orc.msm_affine(gs, sc_all)
+            cpu_dt = (time.perf_counter() - t0) / args.cpu_msms
+            assert out.tolist() == want.tolist(), "GPU MSM differs from the CPU restatement"
+            result["bit_exact_vs_cpu"] = True
+            result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port",
+                                      "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
+                                      "host_cpus": os.cpu_count()}
+        if args.open_steps > 0:
+            d = n - 1
+            coeffs, s = orc.rng_scalars(0x48414C4F00000003, n)
+            zw, _ = orc.rng_scalars(s, 2)
+            C = pcdl.commit(ctx, coeffs, d)
+            pi = pcdl.open(ctx, [1], coeffs, C, d, zw[0])  # warm-up
+            v = ctx.poly_eval(coeffs, zw[0])
+            ctx.prof_enable(2); ctx.prof_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.open_steps):
+                pi = pcdl.open(ctx, [1], coeffs, C, d, zw[0])
+                pcdl.check_proof(ctx, C, d, zw[0], v, pi)
+            torch.cuda.synchronize()
+            odt = (time.perf_counter() - t0) / args.open_steps
+            prof = ctx.prof()
+            ctx.prof_enable(0)
+            fold_ms = prof.get("k_fold_points", (0.0, 0))[0] / args.open_steps
+            result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False,
+                                          "algorithmic_bytes": 480 * n, "hbm_roofline_frac": (480 * n / odt) / (HBM_PEAK_GBS * 1e9),
+                                          "k_fold_points_ms_per_open": fold_ms}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

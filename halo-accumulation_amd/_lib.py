@@ -80,6 +80,7 @@ _SIGS = {
     "halo_prof_count": (C.c_int, [C.c_void_p]),
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
 }
@@ -226,7 +227,8 @@ class Context:
         return out
 
     # ---- measurement
-    def prof_enable(self, on=True):
+    def prof_enable(self, on=1):
+        """1: every launch; 2: dominant kernels only; 0: off"""
         check(self.lib.halo_prof_enable(self.h, int(on)))
 
     def prof_reset(self):
@@ -294,6 +296,14 @@ class Ipa:
             self.close()
         except Exception:
             pass
+
+
+def point_sum(pts_jac):
+    """Sum of Jacobian points in index order (host): the combine step of the sharded MSM."""
+    pts_jac = np.ascontiguousarray(pts_jac, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    check(load().halo_point_sum(ptr(pts_jac), pts_jac.shape[0], ptr(out)))
+    return out
 
 
 def public_points():

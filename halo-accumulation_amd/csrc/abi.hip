@@ -400,6 +400,7 @@ int halo_prof_enable(halo_ctx *ctx, int on) {
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof.collect();
     ctx->prof.on = on != 0;
+    ctx->prof.dominant_only = on == 2;
     return HALO_OK;
 }
 int halo_prof_reset(halo_ctx *ctx) {
@@ -415,6 +416,13 @@ int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, lon
     if (name) *name = ctx->prof.entries[i].name;
     if (total_ms) *total_ms = ctx->prof.entries[i].total_ms;
     if (launches) *launches = ctx->prof.entries[i].launches;
+    return HALO_OK;
+}
+int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
+    if (!out || (k && !pts_jac)) { set_error("point_sum: null pointer"); return HALO_E_ARG; }
+    host::Point acc = host::Point::infinity();
+    for (size_t i = 0; i < k; ++i) acc = acc + host::Point::load(pts_jac + 12 * i);  // fixed rank order 0..k-1
+    acc.store_normalized(out);
     return HALO_OK;
 }
 int halo_set_window_bits(halo_ctx *ctx, int c) {

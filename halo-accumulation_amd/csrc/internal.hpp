@@ -28,6 +28,7 @@ struct ProfEntry {
 
 struct Profiler {
     bool on = false;
+    bool dominant_only = false;  // bracket only k_msm_accumulate / k_fold_points (2 events per MSM)
     std::vector<ProfEntry> entries;
     struct Pending { int idx; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -38,12 +39,14 @@ struct Profiler {
     void collect();  // needs the stream to be idle
 };
 
+inline bool prof_is_dominant(const char *name) { return name[2] == 'm' ? name[6] == 'a' : (name[2] == 'f' && name[7] == 'p'); }
 // Launch wrapper: brackets the launch with events when profiling is on.
 #define HALO_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
     do {                                                                                     \
-        if ((ctx)->prof.on) (ctx)->prof.begin(name, (ctx)->stream);                          \
+        bool _p = (ctx)->prof.on && (!(ctx)->prof.dominant_only || halo::prof_is_dominant(name)); \
+        if (_p) (ctx)->prof.begin(name, (ctx)->stream);                                      \
         hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);          \
-        if ((ctx)->prof.on) (ctx)->prof.end((ctx)->stream);                                  \
+        if (_p) (ctx)->prof.end((ctx)->stream);                                              \
     } while (0)
 
 struct MsmPlan {

@@ -131,12 +131,15 @@ int halo_acc_decider(halo_ctx *ctx, const uint64_t *acc);
 int halo_random_instance(halo_ctx *ctx, uint64_t *rng_state, size_t d, uint64_t *instance_out);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */
-/* When enabled, every kernel launch on this ctx is bracketed by hipEvents on the ctx stream. */
+/* on = 1: every kernel launch on this ctx is bracketed by hipEvents on the ctx stream;
+ * on = 2: only the dominant kernels (k_msm_accumulate, k_fold_points); 0: off. */
 int halo_prof_enable(halo_ctx *ctx, int on);
 int halo_prof_reset(halo_ctx *ctx);
 /* number of distinct kernels seen; name/total ms/launch count of entry i */
 int halo_prof_count(halo_ctx *ctx);
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
+/* sum of k Jacobian points in index order, on the host (combine step of the sharded MSM) */
+int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]);
 /* MSM tuning: window bits (0 = automatic) */
 int halo_set_window_bits(halo_ctx *ctx, int c);
 

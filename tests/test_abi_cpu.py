@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/halo_accumulation.h declares, its host-only entry points are right, and every
+compute entry point fails loudly (no CPU fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hal():
+    import halo_accumulation_amd as h
+    h.build()
+    return h
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "halo_accumulation.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(halo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(hal):
+    lib = C.CDLL(hal._lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+    # and the Python binding covers the same set
+    assert sorted(hal._lib.declared_symbols()) == syms
+
+
+def test_public_points_match_consts_rs(hal, kat):
+    S, H = hal._lib.public_points()
+    hx = lambda p: ["%064x" % p[0], "%064x" % p[1]]
+    assert hx(orc.point_canonical(S)) == kat["S"]
+    assert hx(orc.point_canonical(H)) == kat["H"]
+
+
+def test_point_sum_host(hal, urs4096):
+    pts = np.zeros((5, 12), dtype=np.uint64)
+    want = None
+    for i in range(5):
+        orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(pts[i]))
+    pts[3, 8:] = 0  # one infinity among them
+    acc = orc.z(12); acc[8:] = 0; acc[0] = 1; acc[4] = 1
+    acc = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], dtype=np.uint64)
+    for i in range(5):
+        o = orc.z(12); orc.lib().orc_point_add(orc.ptr(acc), orc.ptr(pts[i]), orc.ptr(o)); acc = o
+    assert hal._lib.point_sum(pts).tolist() == acc.tolist()
+    assert orc.point_canonical(hal._lib.point_sum(pts[:0])) is None
+
+
+def test_layout_sizes_agree_with_oracle(hal):
+    lib = hal.load()
+    for lg in (0, 1, 5, 20):
+        assert lib.halo_proof_words(lg) == orc.proof_words(lg)
+        assert lib.halo_instance_words(lg) == orc.instance_words(lg)
+        assert lib.halo_accumulator_words(lg) == orc.acc_words(lg)
+
+
+def test_no_cpu_fallback(hal):
+    lib = hal.load()
+    if lib.halo_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hal.HaloError) as e:
+        hal._lib.Context(urs_n=64)
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(hal.HaloError):
+        hal._lib.Context(np.zeros((4, 8), dtype=np.uint64))
+    # null handles are rejected, not dereferenced
+    out = np.zeros(12, dtype=np.uint64)
+    assert lib.halo_msm(None, 0, 0, None, 1, hal._lib.ptr(out)) == hal._lib.HALO_E_ARG
+    assert lib.halo_ipa_finish(None, hal._lib.ptr(out), hal._lib.ptr(out)) == hal._lib.HALO_E_ARG
+
+
+def test_product_does_not_import_oracle():
+    """The product path may not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "halo-accumulation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_obj" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import orc" not in text and "pallas_model" not in text and "liborc" not in text and "halo_cpu" not in text, f

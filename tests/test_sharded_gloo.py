@@ -1,0 +1,73 @@
+"""N > 1 path of the sharded MSM on CPU: world_size 2 (and 3, uneven shards) over gloo.
+
+The per-rank Pippenger runs on the GPU in production; here the partial comes from the oracle so
+that the sharding, the all-gather and the fixed-order combine are exercised without a device."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd.sharded import ShardedMsm, shard_range
+    import orc
+    lo, hi = shard_range(n, rank, world)
+    gs = orc.urs_affine(2 + lo, hi - lo)              # this rank's block of the key
+    sc, _ = orc.rng_scalars(0x48414C4F00000005, n)    # every rank derives the same scalar stream
+    msm = ShardedMsm(lambda: orc.msm_affine(gs, np.ascontiguousarray(sc[lo:hi])), h._lib.point_sum)
+    out = msm()
+    q.put((rank, out.tolist(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 101)])
+def test_sharded_msm_gloo(world, n):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gs = orc.urs_affine(2, n)
+    sc, _ = orc.rng_scalars(0x48414C4F00000005, n)
+    want = orc.msm_affine(gs, sc).tolist()
+    ranges = sorted(r[2] for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for rank, out, _ in res:
+        assert out == want, "rank %d disagrees" % rank
+
+
+def test_shard_range_partition():
+    from halo_accumulation_amd.sharded import shard_range
+    for n in (0, 1, 7, 8, 1 << 20):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
