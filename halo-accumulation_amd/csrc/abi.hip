@@ -63,11 +63,11 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     ctx->device = device;
     ctx->n = n;
     HALO_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 64));
+    HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 80));
     size_t tn = n < 64 ? 64 : n;
     ctx->tmp_words = tn * 12;
     HALO_HIP(hipMalloc(&ctx->d_tmp_a, tn * 12 * 8));
-    HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 8 * 8));
+    HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 10 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
     return msm_workspace_alloc(ctx, n);
@@ -104,9 +104,9 @@ int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, cons
     st->n = st->m = n;
     int rc = HALO_OK;
     do {
-        if (hipMalloc(&st->d_G, n * 64) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
+        if (hipMalloc(&st->d_G, n * 80) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
             hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
-        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 64, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 80, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
         }
@@ -139,7 +139,9 @@ int halo_ctx_create(int device, const uint64_t *bases_affine, size_t n, halo_ctx
     halo_ctx *ctx = new (std::nothrow) halo_ctx();
     if (!ctx) { set_error("out of host memory"); return HALO_E_ARG; }
     int rc = ctx_alloc_common(ctx, device, n);
-    if (rc == HALO_OK) rc = upload(ctx, ctx->d_bases, bases_affine, n * 8);
+    if (rc == HALO_OK) rc = upload(ctx, ctx->d_tmp_a, bases_affine, n * 8);
+    if (rc == HALO_OK) rc = aff_words_to_native(ctx, ctx->d_tmp_a, n, ctx->d_bases);
+    if (rc == HALO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HALO_E_DEVICE;
     if (rc != HALO_OK) { halo_ctx_destroy(ctx); return rc; }
     *out = ctx;
     return HALO_OK;
@@ -181,7 +183,9 @@ void *halo_ctx_stream(halo_ctx *ctx) { return ctx ? (void *)ctx->stream : nullpt
 int halo_ctx_read_bases(halo_ctx *ctx, size_t off, size_t n, uint64_t *out) {
     HALO_CTX(ctx);
     if (off + n > ctx->n || !out) { set_error("read_bases: range"); return HALO_E_ARG; }
-    return download(ctx, out, ctx->d_bases + 8 * off, n * 8);
+    int rc = aff_native_to_words(ctx, ctx->d_bases + 20 * off, n, ctx->d_tmp_a);
+    if (rc) return rc;
+    return download(ctx, out, ctx->d_tmp_a, n * 8);
 }
 
 int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]) {
@@ -196,7 +200,7 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
     HALO_CTX(ctx);
     if (off + n > ctx->n || !out || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     host::Point r;
-    int rc = msm_run(ctx, ctx->d_bases + 8 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n, &r);
+    int rc = msm_run(ctx, ctx->d_bases + 20 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -216,13 +220,13 @@ int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scal
     if (!out || (m && (!pts_jac || !scalars))) { set_error("msm_points: null pointer"); return HALO_E_ARG; }
     int rc = upload(ctx, ctx->d_tmp_a, pts_jac, m * 12);
     if (rc) return rc;
-    rc = batch_to_affine(ctx, ctx->d_tmp_a, m, ctx->d_tmp_b);
+    rc = batch_to_affine(ctx, ctx->d_tmp_a, m, reinterpret_cast<uint32_t *>(ctx->d_tmp_b));
     if (rc) return rc;
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     rc = upload(ctx, ctx->d_tmp_a, scalars, m * 4);
     if (rc) return rc;
     host::Point r;
-    rc = msm_run(ctx, ctx->d_tmp_b, ctx->d_tmp_a, true, m, &r);
+    rc = msm_run(ctx, reinterpret_cast<const uint32_t *>(ctx->d_tmp_b), ctx->d_tmp_a, true, m, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -346,7 +350,7 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     host::Point Hp = host::Point::load(H_prime), Lp, Rp;
     rc = msm_run(ctx, st->d_G, st->d_c + 4 * m, true, m, &Lp);  // <c_r, G_l>
     if (rc) return rc;
-    rc = msm_run(ctx, st->d_G + 8 * m, st->d_c, true, m, &Rp);  // <c_l, G_r>
+    rc = msm_run(ctx, st->d_G + 20 * m, st->d_c, true, m, &Rp);  // <c_l, G_r>
     if (rc) return rc;
     (Lp + Hp.mul(dots[0])).store_normalized(L);
     (Rp + Hp.mul(dots[1])).store_normalized(R);
@@ -373,7 +377,8 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     HALO_CTX(ctx);
     if (st->m != 1) { set_error("ipa_finish: rounds remaining"); return HALO_E_ARG; }
     uint64_t g[8];
-    int rc = download(ctx, g, st->d_G, 8);
+    int rc = aff_native_to_words(ctx, st->d_G, 1, ctx->d_tmp_a);
+    if (!rc) rc = download(ctx, g, ctx->d_tmp_a, 8);
     if (!rc) rc = download(ctx, c, st->d_c, 4);
     if (rc) return rc;
     if (ctx->prof.on) ctx->prof.collect();

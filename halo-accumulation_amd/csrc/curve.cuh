@@ -1,193 +1,273 @@
-// Pallas group law on gfx950 (y^2 = x^3 + 5 over Fq, prime order, cofactor 1; group.rs:7-8).
+// Pallas group law on gfx950 (y^2 = x^3 + 5 over Fq, prime order, cofactor 1; group.rs:7-8)
+// over the lazy radix-2^29 field of fq29.cuh.  The integer template argument of Fq<K> is the
+// proven bound "value < K*p"; the invariants of the point types below are what makes every
+// product satisfy Ka*Kb <= 120 (checked at compile time):
 //
-//  Aff  : affine (x, y), (0,0) encodes the point at infinity ((0,0) is not on the curve)
-//  Jac  : Jacobian (X:Y:Z), x = X/Z^2, y = Y/Z^3, Z = 0 infinity  -- what ark-ec's Projective holds;
-//         used for the uniform-scalar ladders (doubling is 2M+5S)
-//  Xyzz : extended Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, ZZ = 0 infinity -- bucket
-//         accumulators (mixed add 8M+2S, full add 12M+2S)
+//  AffN  : affine (x, y), x, y < 2p.  All-zero limbs = point at infinity.  This is also the
+//          layout of the base tables in HBM: 20 words per point (9 limbs + 1 pad per coordinate).
+//  XyzzN : extended Jacobian (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ; X, Y < 8p, ZZ, ZZZ < 2p.
+//          ZZ with all-zero limbs = infinity.  Bucket accumulators: mixed add 8M + 2S, no
+//          reduction step anywhere in it.
+//  JacN  : Jacobian (X:Y:Z); X, Y < 8p, Z < 4p; Z all-zero limbs = infinity.  Uniform-scalar
+//          ladders (doubling 3M + 4S).
 //
 // Every routine is complete: infinity operands, P + P and P + (-P) are handled, because the
 // reference's results must be reproduced for adversarial inputs too (all-equal bases, +s/-s
-// pairs, zero scalars; SURVEY.md section 7 "edge cases").
+// pairs, zero scalars).  The P = +-Q tests are exact: k*p = k (mod 2^29), so a cheap test on
+// limb 0 filters all but ~K/2^29 of the cases before the full reduction.
 #pragma once
-#include "field.cuh"
+#include "fq29.cuh"
 
 namespace halo {
 
 using Q = FqCfg;
 
-struct Aff { Fe x, y; };
-struct Jac { Fe x, y, z; };
-struct Xyzz { Fe x, y, zz, zzz; };
+struct AffN { Fq<2> x, y; };
+struct XyzzN { Fq<8> x, y; Fq<2> zz, zzz; };
+struct JacN { Fq<8> x, y; Fq<4> z; };
 
-HALO_DEV bool aff_is_inf(const Aff &p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
-HALO_DEV Aff aff_inf() { Aff r; r.x = fe_zero(); r.y = fe_zero(); return r; }
-HALO_DEV Aff aff_cneg(const Aff &p, bool negate) {
-    Aff r; r.x = p.x;
-    Fe ny = fe_neg<Q>(p.y);
+constexpr int AFF_WORDS = 20;   // native affine point in memory
+constexpr int XYZZ_WORDS = 40;  // native XYZZ point in memory
+
+// ---------------------------------------------------------------- affine
+HALO_DEV bool aff_is_inf(const AffN &p) { return fq_limbs_zero(p.x) && fq_limbs_zero(p.y); }
+HALO_DEV AffN aff_inf() { AffN r; r.x = fq_zero<2>(); r.y = fq_zero<2>(); return r; }
+HALO_DEV AffN aff_cneg(const AffN &p, bool negate) {
+    AffN r; r.x = p.x;
+    Fq<2> ny = fq_neg<2>(p.y);
+    negate = negate && !fq_limbs_zero(p.y);  // the (0,0) infinity marker must stay (0,0)
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.y.v[i] = negate ? ny.v[i] : p.y.v[i];
+    for (int i = 0; i < 9; i++) r.y.v[i] = negate ? ny.v[i] : p.y.v[i];
     return r;
 }
-HALO_DEV Aff aff_load(const uint64_t *p) { Aff r; r.x = fe_load(p); r.y = fe_load(p + 4); return r; }
-HALO_DEV void aff_store(uint64_t *p, const Aff &a) { fe_store(p, a.x); fe_store(p + 4, a.y); }
+HALO_DEV AffN aff_load(const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    AffN r;
+    r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+    r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+    r.x.v[8] = c.x;
+    r.y.v[0] = c.z; r.y.v[1] = c.w;
+    r.y.v[2] = d.x; r.y.v[3] = d.y; r.y.v[4] = d.z; r.y.v[5] = d.w;
+    r.y.v[6] = e.x; r.y.v[7] = e.y; r.y.v[8] = e.z;
+    return r;
+}
+HALO_DEV void aff_store(uint32_t *p, const AffN &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+    q[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+    q[2] = make_uint4(a.x.v[8], 0u, a.y.v[0], a.y.v[1]);
+    q[3] = make_uint4(a.y.v[2], a.y.v[3], a.y.v[4], a.y.v[5]);
+    q[4] = make_uint4(a.y.v[6], a.y.v[7], a.y.v[8], 0u);
+}
+// arkworks affine words (x | y, 8 u64, (0,0) = infinity) <-> native
+HALO_DEV AffN aff_from_words(const uint64_t *w) {
+    Fe x = fe_load(w), y = fe_load(w + 4);
+    if (fe_is_zero(x) && fe_is_zero(y)) return aff_inf();
+    AffN r; r.x = fq_from_words(x); r.y = fq_from_words(y); return r;
+}
+HALO_DEV void aff_to_words(uint64_t *w, const AffN &a) {
+    if (aff_is_inf(a)) { fe_store(w, fe_zero()); fe_store(w + 4, fe_zero()); return; }
+    fe_store(w, fq_to_words(a.x));
+    fe_store(w + 4, fq_to_words(a.y));
+}
 
 // ---------------------------------------------------------------- XYZZ
-HALO_DEV bool xyzz_is_inf(const Xyzz &p) { return fe_is_zero(p.zz); }
-HALO_DEV Xyzz xyzz_inf() {
-    Xyzz r; r.x = fe_one<Q>(); r.y = fe_one<Q>(); r.zz = fe_zero(); r.zzz = fe_zero(); return r;
+HALO_DEV bool xyzz_is_inf(const XyzzN &p) { return fq_limbs_zero(p.zz); }
+HALO_DEV XyzzN xyzz_inf() {
+    XyzzN r; r.x = fq_zero<8>(); r.y = fq_zero<8>(); r.zz = fq_zero<2>(); r.zzz = fq_zero<2>(); return r;
 }
-HALO_DEV Xyzz xyzz_from_aff(const Aff &a) {
+HALO_DEV XyzzN xyzz_from_aff(const AffN &a) {
     if (aff_is_inf(a)) return xyzz_inf();
-    Xyzz r; r.x = a.x; r.y = a.y; r.zz = fe_one<Q>(); r.zzz = fe_one<Q>(); return r;
+    XyzzN r; r.x = fq_widen<8>(a.x); r.y = fq_widen<8>(a.y);
+    r.zz = fq_widen<2>(fq_one()); r.zzz = r.zz; return r;
 }
-// dbl-2008-s-1, a = 0
-HALO_DEV Xyzz xyzz_dbl(const Xyzz &p) {
-    if (xyzz_is_inf(p)) return p;
-    Fe U = fe_dbl<Q>(p.y);
-    Fe V = fe_sqr<Q>(U);
-    Fe W = fe_mul<Q>(U, V);
-    Fe S = fe_mul<Q>(p.x, V);
-    Fe xx = fe_sqr<Q>(p.x);
-    Fe M = fe_add<Q>(fe_dbl<Q>(xx), xx);
-    Xyzz r;
-    r.x = fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(M), S), S);
-    r.y = fe_sub<Q>(fe_mul<Q>(M, fe_sub<Q>(S, r.x)), fe_mul<Q>(W, p.y));
-    r.zz = fe_mul<Q>(V, p.zz);
-    r.zzz = fe_mul<Q>(W, p.zzz);
+// dbl-2008-s-1, a = 0 (V = 4Y^2, W = 2Y*V, S = X*V, M = 3X^2).  Infinity in -> infinity out.
+HALO_DEV XyzzN xyzz_dbl(const XyzzN &p) {
+    Fq<8> V = fq_muls<4>(fq_sqr(p.y));
+    Fq<4> W = fq_muls<2>(fq_mul(p.y, V));
+    Fq<2> S = fq_mul(p.x, V);
+    Fq<6> M = fq_muls<3>(fq_sqr(p.x));
+    XyzzN r;
+    Fq<6> x3 = fq_sub<4>(fq_sqr(M), fq_muls<2>(S));
+    r.x = fq_widen<8>(x3);
+    r.y = fq_widen<8>(fq_sub<2>(fq_mul(M, fq_sub<8>(S, x3)), fq_mul(W, p.y)));
+    r.zz = fq_mul(V, p.zz);
+    r.zzz = fq_mul(W, p.zzz);
+    if (xyzz_is_inf(p)) return xyzz_inf();
     return r;
 }
-// madd-2008-s: acc += q (affine)
-HALO_DEV void xyzz_madd(Xyzz &acc, const Aff &q) {
+// madd-2008-s: acc += q (affine).  8M + 2S, five carry passes, no reduction.
+HALO_DEV void xyzz_madd(XyzzN &acc, const AffN &q) {
     if (aff_is_inf(q)) return;
     if (xyzz_is_inf(acc)) { acc = xyzz_from_aff(q); return; }
-    Fe U2 = fe_mul<Q>(q.x, acc.zz);
-    Fe S2 = fe_mul<Q>(q.y, acc.zzz);
-    Fe Pd = fe_sub<Q>(U2, acc.x);
-    Fe Rd = fe_sub<Q>(S2, acc.y);
-    if (fe_is_zero(Pd)) {
-        if (fe_is_zero(Rd)) acc = xyzz_dbl(xyzz_from_aff(q));
+    Fq<2> U2 = fq_mul(q.x, acc.zz);
+    Fq<2> S2 = fq_mul(q.y, acc.zzz);
+    Fq<10> Pd = fq_sub<8>(U2, acc.x);
+    Fq<10> Rd = fq_sub<8>(S2, acc.y);
+    if (fq_is_zero_modp(Pd)) {
+        if (fq_is_zero_modp(Rd)) acc = xyzz_dbl(xyzz_from_aff(q));
         else acc = xyzz_inf();
         return;
     }
-    Fe PP = fe_sqr<Q>(Pd);
-    Fe PPP = fe_mul<Q>(Pd, PP);
-    Fe Qv = fe_mul<Q>(acc.x, PP);
-    Fe x3 = fe_sub<Q>(fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(Rd), PPP), Qv), Qv);
-    Fe y3 = fe_sub<Q>(fe_mul<Q>(Rd, fe_sub<Q>(Qv, x3)), fe_mul<Q>(acc.y, PPP));
+    Fq<2> PP = fq_sqr(Pd);
+    Fq<2> PPP = fq_mul(Pd, PP);
+    Fq<2> Qv = fq_mul(acc.x, PP);
+    Fq<8> x3 = fq_sub_sub2(fq_sqr(Rd), PPP, Qv);
+    Fq<4> y3 = fq_sub<2>(fq_mul(Rd, fq_sub<8>(Qv, x3)), fq_mul(acc.y, PPP));
     acc.x = x3;
-    acc.y = y3;
-    acc.zz = fe_mul<Q>(acc.zz, PP);
-    acc.zzz = fe_mul<Q>(acc.zzz, PPP);
+    acc.y = fq_widen<8>(y3);
+    acc.zz = fq_mul(acc.zz, PP);
+    acc.zzz = fq_mul(acc.zzz, PPP);
 }
-// add-2008-s: acc += q
-HALO_DEV void xyzz_add(Xyzz &acc, const Xyzz &q) {
+// add-2008-s: acc += q.  12M + 2S.
+HALO_DEV void xyzz_add(XyzzN &acc, const XyzzN &q) {
     if (xyzz_is_inf(q)) return;
     if (xyzz_is_inf(acc)) { acc = q; return; }
-    Fe U1 = fe_mul<Q>(acc.x, q.zz);
-    Fe U2 = fe_mul<Q>(q.x, acc.zz);
-    Fe S1 = fe_mul<Q>(acc.y, q.zzz);
-    Fe S2 = fe_mul<Q>(q.y, acc.zzz);
-    Fe Pd = fe_sub<Q>(U2, U1);
-    Fe Rd = fe_sub<Q>(S2, S1);
-    if (fe_is_zero(Pd)) {
-        if (fe_is_zero(Rd)) acc = xyzz_dbl(acc);
+    Fq<2> U1 = fq_mul(acc.x, q.zz);
+    Fq<2> U2 = fq_mul(q.x, acc.zz);
+    Fq<2> S1 = fq_mul(acc.y, q.zzz);
+    Fq<2> S2 = fq_mul(q.y, acc.zzz);
+    Fq<4> Pd = fq_sub<2>(U2, U1);
+    Fq<4> Rd = fq_sub<2>(S2, S1);
+    if (fq_is_zero_modp(Pd)) {
+        if (fq_is_zero_modp(Rd)) acc = xyzz_dbl(acc);
         else acc = xyzz_inf();
         return;
     }
-    Fe PP = fe_sqr<Q>(Pd);
-    Fe PPP = fe_mul<Q>(Pd, PP);
-    Fe Qv = fe_mul<Q>(U1, PP);
-    Fe x3 = fe_sub<Q>(fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(Rd), PPP), Qv), Qv);
-    Fe y3 = fe_sub<Q>(fe_mul<Q>(Rd, fe_sub<Q>(Qv, x3)), fe_mul<Q>(S1, PPP));
+    Fq<2> PP = fq_sqr(Pd);
+    Fq<2> PPP = fq_mul(Pd, PP);
+    Fq<2> Qv = fq_mul(U1, PP);
+    Fq<8> x3 = fq_sub_sub2(fq_sqr(Rd), PPP, Qv);
+    Fq<4> y3 = fq_sub<2>(fq_mul(Rd, fq_sub<8>(Qv, x3)), fq_mul(S1, PPP));
     acc.x = x3;
-    acc.y = y3;
-    acc.zz = fe_mul<Q>(fe_mul<Q>(acc.zz, q.zz), PP);
-    acc.zzz = fe_mul<Q>(fe_mul<Q>(acc.zzz, q.zzz), PPP);
+    acc.y = fq_widen<8>(y3);
+    acc.zz = fq_mul(fq_mul(acc.zz, q.zz), PP);
+    acc.zzz = fq_mul(fq_mul(acc.zzz, q.zzz), PPP);
 }
-// (X, Y, ZZ, ZZZ) -> Jacobian with Z = ZZZ: X*ZZ^2, Y*ZZZ^2, ZZZ   (ZZ^3 = ZZZ^2)
-HALO_DEV Jac xyzz_to_jac(const Xyzz &p) {
-    Jac r;
-    if (xyzz_is_inf(p)) { r.x = fe_one<Q>(); r.y = fe_one<Q>(); r.z = fe_zero(); return r; }
-    r.x = fe_mul<Q>(p.x, fe_sqr<Q>(p.zz));
-    r.y = fe_mul<Q>(p.y, fe_sqr<Q>(p.zzz));
-    r.z = p.zzz;
+// native XYZZ in memory: x | y | zz | zzz, 10 words each
+HALO_DEV void xyzz_store(uint32_t *o, const XyzzN &p) {
+    fq_store_native(o, p.x); fq_store_native(o + 10, p.y); fq_store_native(o + 20, p.zz); fq_store_native(o + 30, p.zzz);
+}
+template <int K>
+HALO_DEV Fq<K> fq_load_native(const uint32_t *p) {
+    Fq<K> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = p[i];
     return r;
 }
-HALO_DEV void jac_store(uint64_t *o, const Jac &p) { fe_store(o, p.x); fe_store(o + 4, p.y); fe_store(o + 8, p.z); }
-HALO_DEV Jac jac_load(const uint64_t *o) { Jac p; p.x = fe_load(o); p.y = fe_load(o + 4); p.z = fe_load(o + 8); return p; }
-HALO_DEV void xyzz_store(uint64_t *o, const Xyzz &p) { fe_store(o, p.x); fe_store(o + 4, p.y); fe_store(o + 8, p.zz); fe_store(o + 12, p.zzz); }
-HALO_DEV Xyzz xyzz_load(const uint64_t *o) { Xyzz p; p.x = fe_load(o); p.y = fe_load(o + 4); p.zz = fe_load(o + 8); p.zzz = fe_load(o + 12); return p; }
+HALO_DEV XyzzN xyzz_load(const uint32_t *o) {
+    XyzzN p;
+    p.x = fq_load_native<8>(o); p.y = fq_load_native<8>(o + 10); p.zz = fq_load_native<2>(o + 20); p.zzz = fq_load_native<2>(o + 30);
+    return p;
+}
+// (X, Y, ZZ, ZZZ) -> arkworks Jacobian words with Z = ZZZ: X*ZZ^2, Y*ZZZ^2, ZZZ   (ZZ^3 = ZZZ^2)
+HALO_DEV void xyzz_store_jac_words(uint64_t *o, const XyzzN &p) {
+    if (xyzz_is_inf(p)) {
+        fe_store(o, fe_one<Q>()); fe_store(o + 4, fe_one<Q>()); fe_store(o + 8, fe_zero());
+        return;
+    }
+    fe_store(o, fq_to_words(fq_mul(p.x, fq_sqr(p.zz))));
+    fe_store(o + 4, fq_to_words(fq_mul(p.y, fq_sqr(p.zzz))));
+    fe_store(o + 8, fq_to_words(p.zzz));
+}
 
 // ---------------------------------------------------------------- Jacobian
-HALO_DEV bool jac_is_inf(const Jac &p) { return fe_is_zero(p.z); }
-HALO_DEV Jac jac_inf() { Jac r; r.x = fe_one<Q>(); r.y = fe_one<Q>(); r.z = fe_zero(); return r; }
-HALO_DEV Jac jac_from_aff(const Aff &a) {
+HALO_DEV bool jac_is_inf(const JacN &p) { return fq_limbs_zero(p.z); }
+HALO_DEV JacN jac_inf() { JacN r; r.x = fq_zero<8>(); r.y = fq_zero<8>(); r.z = fq_zero<4>(); return r; }
+HALO_DEV JacN jac_from_aff(const AffN &a) {
     if (aff_is_inf(a)) return jac_inf();
-    Jac r; r.x = a.x; r.y = a.y; r.z = fe_one<Q>(); return r;
+    JacN r; r.x = fq_widen<8>(a.x); r.y = fq_widen<8>(a.y); r.z = fq_widen<4>(fq_one()); return r;
 }
-// dbl-2009-l (a = 0): 2M + 5S.  Infinity in -> infinity out (Z3 = 2*Y*0).
-HALO_DEV Jac jac_dbl(const Jac &p) {
-    Fe A = fe_sqr<Q>(p.x);
-    Fe B = fe_sqr<Q>(p.y);
-    Fe C = fe_sqr<Q>(B);
-    Fe t = fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(fe_add<Q>(p.x, B)), A), C);
-    Fe D = fe_dbl<Q>(t);
-    Fe E = fe_add<Q>(fe_dbl<Q>(A), A);
-    Fe F = fe_sqr<Q>(E);
-    Jac r;
-    r.z = fe_dbl<Q>(fe_mul<Q>(p.y, p.z));
-    r.x = fe_sub<Q>(fe_sub<Q>(F, D), D);
-    Fe c8 = fe_dbl<Q>(fe_dbl<Q>(fe_dbl<Q>(C)));
-    r.y = fe_sub<Q>(fe_mul<Q>(E, fe_sub<Q>(D, r.x)), c8);
+// dbl-2009-l with D = 4*X*Y^2 computed as a product: 3M + 4S.  Infinity in -> infinity out (Z3 = 2*Y*0).
+HALO_DEV JacN jac_dbl(const JacN &p) {
+    Fq<2> A = fq_sqr(p.x);
+    Fq<2> B = fq_sqr(p.y);
+    Fq<2> C = fq_sqr(B);
+    Fq<8> D = fq_muls<4>(fq_mul(p.x, B));
+    Fq<6> E = fq_muls<3>(A);
+    Fq<2> F = fq_sqr(E);
+    JacN r;
+    Fq<2> x3 = fq_tighten(fq_sub<16>(F, fq_muls<2>(D)));
+    Fq<2> c8 = fq_tighten(fq_muls<8>(C));
+    r.x = fq_widen<8>(x3);
+    r.y = fq_widen<8>(fq_sub<2>(fq_mul(E, fq_sub<2>(D, x3)), c8));
+    r.z = fq_muls<2>(fq_mul(p.y, p.z));
     return r;
 }
-// madd-2007-bl: p + q (affine): 7M + 4S
-HALO_DEV Jac jac_madd(const Jac &p, const Aff &q) {
+// madd-2007-bl with Z3 = 2*Z1*H and r = 2*r0 factored: 8M + 3S
+HALO_DEV JacN jac_madd(const JacN &p, const AffN &q) {
     if (aff_is_inf(q)) return p;
     if (jac_is_inf(p)) return jac_from_aff(q);
-    Fe Z1Z1 = fe_sqr<Q>(p.z);
-    Fe U2 = fe_mul<Q>(q.x, Z1Z1);
-    Fe S2 = fe_mul<Q>(fe_mul<Q>(q.y, p.z), Z1Z1);
-    Fe H = fe_sub<Q>(U2, p.x);
-    Fe rr = fe_sub<Q>(S2, p.y);
-    if (fe_is_zero(H)) {
-        if (fe_is_zero(rr)) return jac_dbl(p);
+    Fq<2> Z1Z1 = fq_sqr(p.z);
+    Fq<2> U2 = fq_mul(q.x, Z1Z1);
+    Fq<2> S2 = fq_mul(fq_mul(q.y, p.z), Z1Z1);
+    Fq<10> H = fq_sub<8>(U2, p.x);
+    Fq<10> r0 = fq_sub<8>(S2, p.y);
+    if (fq_is_zero_modp(H)) {
+        if (fq_is_zero_modp(r0)) return jac_dbl(p);
         return jac_inf();
     }
-    rr = fe_dbl<Q>(rr);
-    Fe HH = fe_sqr<Q>(H);
-    Fe I = fe_dbl<Q>(fe_dbl<Q>(HH));
-    Fe J = fe_mul<Q>(H, I);
-    Fe V = fe_mul<Q>(p.x, I);
-    Jac r;
-    r.x = fe_sub<Q>(fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(rr), J), V), V);
-    r.y = fe_sub<Q>(fe_mul<Q>(rr, fe_sub<Q>(V, r.x)), fe_dbl<Q>(fe_mul<Q>(p.y, J)));
-    r.z = fe_sub<Q>(fe_sub<Q>(fe_sqr<Q>(fe_add<Q>(p.z, H)), Z1Z1), HH);
+    Fq<8> I = fq_muls<4>(fq_sqr(H));
+    Fq<2> J = fq_mul(H, I);
+    Fq<2> V = fq_mul(p.x, I);
+    Fq<2> x3 = fq_tighten(fq_sub_sub2(fq_muls<4>(fq_sqr(r0)), J, V));
+    JacN r;
+    r.x = fq_widen<8>(x3);
+    r.y = fq_muls<2>(fq_sub<2>(fq_mul(r0, fq_sub<2>(V, x3)), fq_mul(p.y, J)));
+    r.z = fq_muls<2>(fq_mul(p.z, H));
     return r;
 }
 // Jacobian -> affine with one Fermat inversion
-HALO_DEV Aff jac_to_aff(const Jac &p) {
+HALO_DEV AffN jac_to_aff(const JacN &p) {
     if (jac_is_inf(p)) return aff_inf();
-    Fe zi = fe_inv<Q>(p.z);
-    Fe zi2 = fe_sqr<Q>(zi);
-    Aff r;
-    r.x = fe_mul<Q>(p.x, zi2);
-    r.y = fe_mul<Q>(p.y, fe_mul<Q>(zi2, zi));
+    Fq<2> zi = fq_inv(p.z);
+    Fq<2> zi2 = fq_sqr(zi);
+    AffN r;
+    r.x = fq_mul(p.x, zi2);
+    r.y = fq_mul(p.y, fq_mul(zi2, zi));
     return r;
+}
+// arkworks Jacobian words <-> native
+HALO_DEV JacN jac_from_words(const uint64_t *o) {
+    Fe z = fe_load(o + 8);
+    if (fe_is_zero(z)) return jac_inf();
+    JacN r;
+    r.x = fq_widen<8>(fq_from_words(fe_load(o)));
+    r.y = fq_widen<8>(fq_from_words(fe_load(o + 4)));
+    r.z = fq_widen<4>(fq_from_words(z));
+    return r;
+}
+HALO_DEV void jac_store_words(uint64_t *o, const JacN &p) {
+    if (jac_is_inf(p)) {
+        fe_store(o, fe_one<Q>()); fe_store(o + 4, fe_one<Q>()); fe_store(o + 8, fe_zero());
+        return;
+    }
+    fe_store(o, fq_to_words(p.x)); fe_store(o + 4, fq_to_words(p.y)); fe_store(o + 8, fq_to_words(p.z));
+}
+HALO_DEV XyzzN jac_to_xyzz(const JacN &p) {
+    if (jac_is_inf(p)) return xyzz_inf();
+    XyzzN r; r.x = p.x; r.y = p.y; r.zz = fq_sqr(p.z); r.zzz = fq_mul(r.zz, p.z); return r;
 }
 
 // ---------------------------------------------------------------- cross-lane moves (wave64)
+template <int K>
+HALO_DEV Fq<K> fq_shfl(const Fq<K> &a, int src_lane) {
+    Fq<K> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = (uint32_t)__shfl((int)a.v[i], src_lane, 64);
+    return r;
+}
+HALO_DEV XyzzN xyzz_shfl(const XyzzN &p, int src_lane) {
+    XyzzN r;
+    r.x = fq_shfl(p.x, src_lane); r.y = fq_shfl(p.y, src_lane);
+    r.zz = fq_shfl(p.zz, src_lane); r.zzz = fq_shfl(p.zzz, src_lane);
+    return r;
+}
 HALO_DEV Fe fe_shfl(const Fe &a, int src_lane) {
     Fe r;
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl((int)a.v[i], src_lane, 64);
-    return r;
-}
-HALO_DEV Xyzz xyzz_shfl(const Xyzz &p, int src_lane) {
-    Xyzz r;
-    r.x = fe_shfl(p.x, src_lane); r.y = fe_shfl(p.y, src_lane);
-    r.zz = fe_shfl(p.zz, src_lane); r.zzz = fe_shfl(p.zzz, src_lane);
     return r;
 }
 

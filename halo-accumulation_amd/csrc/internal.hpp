@@ -64,9 +64,9 @@ struct MsmWorkspace {
     uint32_t *d_blockoff = nullptr;  // per 4096-entry block offset
     uint32_t *d_cursor = nullptr;    // W*B
     uint32_t *d_sorted = nullptr;    // n*W entries: point index | sign << 31
-    uint64_t *d_buckets = nullptr;   // one XYZZ partial (16 words) per task
+    uint32_t *d_buckets = nullptr;   // one native XYZZ partial (40 words) per task
     uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
-    uint64_t *d_seg = nullptr;       // W*64 x 2 x 16 (S, T per 512-bucket segment)
+    uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
     size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0;
@@ -78,7 +78,7 @@ struct halo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     size_t n = 0;
-    uint64_t *d_bases = nullptr;  // n x 8 affine
+    uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.cuh AffN)
     halo::MsmWorkspace ws;
     halo::Profiler prof;
     int window_bits = 0;
@@ -93,7 +93,7 @@ struct halo_ctx {
 struct halo_ipa {
     halo_ctx *ctx = nullptr;
     size_t n = 0, m = 0;  // m = current length (n, n/2, ...)
-    uint64_t *d_G = nullptr;  // m x 8 affine (in-place)
+    uint32_t *d_G = nullptr;  // m x 20 words native affine (in-place)
     uint64_t *d_c = nullptr;  // m x 4
     uint64_t *d_z = nullptr;  // m x 4
 };
@@ -104,14 +104,17 @@ namespace halo {
 int msm_workspace_alloc(halo_ctx *ctx, size_t n);
 void msm_workspace_free(halo_ctx *ctx);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
-int msm_run(halo_ctx *ctx, const uint64_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);
-int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out_affine);
-int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint64_t *d_out_affine);
+// bases: native affine table (20 words per point)
+int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);
+int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out_native);
+int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac_words, size_t n, uint32_t *d_out_native);
+int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t *d_out);
+int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 
 // ---- ipa.hip
-int ipa_fold_points(halo_ctx *ctx, uint64_t *d_G, size_t m, const host::Fr &xi_mont);
+int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont);
 int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv);
 // out[0] = <xs0, ys0>, out[1] = <xs1, ys1> (either pair may be null to skip)
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,

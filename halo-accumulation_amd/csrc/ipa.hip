@@ -24,12 +24,12 @@ HALO_DEV Fe from_arg(const FeArg &a) {
 }
 
 // ------------------------------------------------------------------ K3: G'[j] = G[j] + xi * G[j+m]
-__global__ __launch_bounds__(256) void k_fold_points(uint64_t *__restrict__ G, uint32_t m, FeArg xi_canon) {
+__global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, uint32_t m, FeArg xi_canon) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
-    Aff hi = aff_load(G + 8 * (size_t)(j + m));
-    Aff lo = aff_load(G + 8 * (size_t)j);
-    Jac acc = jac_inf();
+    AffN hi = aff_load(G + AFF_WORDS * (size_t)(j + m));
+    AffN lo = aff_load(G + AFF_WORDS * (size_t)j);
+    JacN acc = jac_inf();
 #pragma unroll 1
     for (int limb = 7; limb >= 0; limb--) {
         uint32_t word = 0;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_fold_points(uint64_t *__restrict__ G, u
         }
     }
     acc = jac_madd(acc, lo);
-    aff_store(G + 8 * (size_t)j, jac_to_aff(acc));
+    aff_store(G + AFF_WORDS * (size_t)j, jac_to_aff(acc));
 }
 
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const ui
 }
 
 // ================================================================== host launchers
-int ipa_fold_points(halo_ctx *ctx, uint64_t *d_G, size_t m, const host::Fr &xi_mont) {
+int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
     FeArg xi = to_arg(xi_mont.from_mont());
     HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, xi);

@@ -160,11 +160,11 @@ __global__ __launch_bounds__(256) void k_msm_task_meta(const uint32_t *__restric
     if (ntask[g] > 1) biglist[atomicAdd(&meta[1], 1u)] = g;
 }
 
-__global__ __launch_bounds__(256) void k_msm_accumulate(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
                                                         const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
                                                         const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                        uint32_t total_buckets, uint64_t *__restrict__ partial) {
+                                                        uint32_t total_buckets, uint32_t *__restrict__ partial) {
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= meta[0]) return;
     // bucket of task t: last g with toff(g) <= t (ties are empty buckets, which sort before their non-empty successor)
@@ -178,130 +178,141 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint64_t *__restri
     uint32_t cnt = counts[g] - first;
     if (cnt > KMAX) cnt = KMAX;
     uint32_t st = scan_at(starts, blockoff, g) + first;
-    Xyzz acc = xyzz_inf();
+    XyzzN acc = xyzz_inf();
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t e = sorted[st + k];
-        Aff p = aff_load(bases + 8 * (size_t)(e & 0x7fffffffu));
+        AffN p = aff_load(bases + AFF_WORDS * (size_t)(e & 0x7fffffffu));
         p = aff_cneg(p, (e >> 31) != 0);
         xyzz_madd(acc, p);
     }
-    xyzz_store(partial + 16 * (size_t)t, acc);
+    xyzz_store(partial + XYZZ_WORDS * (size_t)t, acc);
 }
 
 // one wave per multi-task bucket (grid-stride over biglist): partial[toff(g)] <- sum of its partials
 __global__ __launch_bounds__(64) void k_msm_combine_big(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
                                                         const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                        const uint32_t *__restrict__ biglist, uint64_t *__restrict__ partial) {
+                                                        const uint32_t *__restrict__ biglist, uint32_t *__restrict__ partial) {
     uint32_t lane = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < meta[1]; b += gridDim.x) {
         uint32_t g = biglist[b];
         uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
-        Xyzz acc = xyzz_inf();
+        XyzzN acc = xyzz_inf();
 #pragma unroll 1
         for (uint32_t j = lane; j < nt; j += 64) {
-            Xyzz q = xyzz_load(partial + 16 * (size_t)(t0 + j));
+            XyzzN q = xyzz_load(partial + XYZZ_WORDS * (size_t)(t0 + j));
             xyzz_add(acc, q);
         }
 #pragma unroll 1
         for (int off = 32; off >= 1; off >>= 1) {
-            Xyzz o = xyzz_shfl(acc, (lane + off) & 63);
+            XyzzN o = xyzz_shfl(acc, (lane + off) & 63);
             if ((int)lane < off) xyzz_add(acc, o);
         }
-        if (lane == 0) xyzz_store(partial + 16 * (size_t)t0, acc);
+        if (lane == 0) xyzz_store(partial + XYZZ_WORDS * (size_t)t0, acc);
     }
 }
 
 // value of bucket g after the combine pass
-HALO_DEV Xyzz bucket_value(const uint64_t *__restrict__ partial, const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
-                           const uint32_t *__restrict__ tblockoff, uint32_t g) {
+HALO_DEV XyzzN bucket_value(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                            const uint32_t *__restrict__ tblockoff, uint32_t g) {
     if (ntask[g] == 0) return xyzz_inf();
-    return xyzz_load(partial + 16 * (size_t)scan_at(toff, tblockoff, g));
+    return xyzz_load(partial + XYZZ_WORDS * (size_t)scan_at(toff, tblockoff, g));
 }
 
 // ------------------------------------------------------------------------------ reduce
 // Lane l holds S (sum of its buckets) and T (their sum weighted 1..L relative to the lane's
 // first bucket).  Returns in lane 0: S_tot = sum_l S_l and T_tot = sum_l (T_l + l * 2^k * S_l).
-HALO_DEV void wave_weighted_sum(Xyzz &S, Xyzz &T, int k) {
+HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k) {
     int lane = threadIdx.x & 63;
     // inclusive suffix scan: S_l <- sum_{j >= l} S_j
 #pragma unroll 1
     for (int off = 1; off < 64; off <<= 1) {
-        Xyzz o = xyzz_shfl(S, (lane + off) & 63);
+        XyzzN o = xyzz_shfl(S, (lane + off) & 63);
         if (lane + off < 64) xyzz_add(S, o);
     }
     // sum_{l>=1} suffix_l = sum_l l * S_l
-    Xyzz V = (lane >= 1) ? S : xyzz_inf();
+    XyzzN V = (lane >= 1) ? S : xyzz_inf();
 #pragma unroll 1
     for (int i = 0; i < k; i++) V = xyzz_dbl(V);
     xyzz_add(T, V);
 #pragma unroll 1
     for (int off = 32; off >= 1; off >>= 1) {
-        Xyzz o = xyzz_shfl(T, (lane + off) & 63);
+        XyzzN o = xyzz_shfl(T, (lane + off) & 63);
         if (lane < off) xyzz_add(T, o);
     }
 }
 
 // one wave per (window, segment of 64*L buckets)
-__global__ __launch_bounds__(64) void k_msm_reduce1(const uint64_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
+__global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
                                                     const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff, uint32_t B,
-                                                    uint32_t L, int logL, uint32_t nseg, uint64_t *__restrict__ seg) {
+                                                    uint32_t L, int logL, uint32_t nseg, uint32_t *__restrict__ seg) {
     uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
     uint32_t lane = threadIdx.x;
     uint32_t first = s * 64 * L + lane * L;
-    Xyzz run = xyzz_inf(), tot = xyzz_inf();
+    XyzzN run = xyzz_inf(), tot = xyzz_inf();
 #pragma unroll 1
     for (int j = (int)L - 1; j >= 0; j--) {
         uint32_t idx = first + (uint32_t)j;
-        Xyzz b = xyzz_inf();
+        XyzzN b = xyzz_inf();
         if (idx < B) b = bucket_value(partial, ntask, toff, tblockoff, w * B + idx);
         xyzz_add(run, b);
         xyzz_add(tot, run);
     }
     wave_weighted_sum(run, tot, logL);
     if (lane == 0) {
-        uint64_t *o = seg + 32 * ((size_t)w * nseg + s);
+        uint32_t *o = seg + 2 * XYZZ_WORDS * ((size_t)w * nseg + s);
         xyzz_store(o, run);
-        xyzz_store(o + 16, tot);
+        xyzz_store(o + XYZZ_WORDS, tot);
     }
 }
 // one wave per window over its nseg <= 64 segments; segment stride = 64*L buckets = 2^seg_shift
-__global__ __launch_bounds__(64) void k_msm_reduce2(const uint64_t *__restrict__ seg, uint32_t nseg, int seg_shift,
+__global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__ seg, uint32_t nseg, int seg_shift,
                                                     uint64_t *__restrict__ winsum) {
     uint32_t w = blockIdx.x, lane = threadIdx.x;
-    Xyzz S = xyzz_inf(), T = xyzz_inf();
+    XyzzN S = xyzz_inf(), T = xyzz_inf();
     if (lane < nseg) {
-        const uint64_t *o = seg + 32 * ((size_t)w * nseg + lane);
+        const uint32_t *o = seg + 2 * XYZZ_WORDS * ((size_t)w * nseg + lane);
         S = xyzz_load(o);
-        T = xyzz_load(o + 16);
+        T = xyzz_load(o + XYZZ_WORDS);
     }
     wave_weighted_sum(S, T, seg_shift);
-    if (lane == 0) jac_store(winsum + 12 * (size_t)w, xyzz_to_jac(T));
+    if (lane == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
 }
 
-// ------------------------------------------------------------------------------ K10 / K11
-__global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint64_t *__restrict__ out) {
+// ------------------------------------------------------------------------------ K10 / K11 / format conversion
+// arkworks Jacobian words -> native affine (one Fermat inversion per lane)
+__global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Jac p = jac_load(jac + 12 * (size_t)i);
-    aff_store(out + 8 * (size_t)i, jac_to_aff(p));
+    aff_store(out + AFF_WORDS * (size_t)i, jac_to_aff(jac_from_words(jac + 12 * (size_t)i)));
+}
+// arkworks affine words (n x 8 u64) -> native table (n x 20 words)
+__global__ __launch_bounds__(256) void k_aff_to_native(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    aff_store(out + AFF_WORDS * (size_t)i, aff_from_words(in + 8 * (size_t)i));
+}
+__global__ __launch_bounds__(256) void k_native_to_aff(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    aff_to_words(out + 8 * (size_t)i, aff_load(in + AFF_WORDS * (size_t)i));
 }
 // table[w][d] = d * 16^w * (-1, 2), d in 0..15 (d = 0 stored as infinity): 64 mixed adds, no doublings
-__global__ __launch_bounds__(256) void k_urs(const uint64_t *__restrict__ table, const uint32_t *__restrict__ canon, uint32_t n,
-                                             uint64_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_urs(const uint32_t *__restrict__ table, const uint32_t *__restrict__ canon, uint32_t n,
+                                             uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Jac acc = jac_inf();
+    JacN acc = jac_inf();
 #pragma unroll 1
     for (int limb = 0; limb < 8; limb++) {
         uint32_t word = canon[8 * (size_t)i + limb];
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             uint32_t nib = (word >> (4 * k)) & 15u;
-            Aff t = aff_load(table + 8 * (size_t)((limb * 8 + k) * 16 + nib));
+            AffN t = aff_load(table + AFF_WORDS * (size_t)((limb * 8 + k) * 16 + nib));
             acc = jac_madd(acc, t);
         }
     }
-    aff_store(out + 8 * (size_t)i, jac_to_aff(acc));
+    aff_store(out + AFF_WORDS * (size_t)i, jac_to_aff(acc));
 }
 
 // ------------------------------------------------------------------------------ test hooks
@@ -322,37 +333,59 @@ __global__ __launch_bounds__(256) void k_test_field(int op, const uint64_t *a, c
     }
     fe_store(out + 4 * (size_t)i, r);
 }
-HALO_DEV Xyzz jac_to_xyzz(const Jac &p) {
-    if (jac_is_inf(p)) return xyzz_inf();
-    Xyzz r; r.x = p.x; r.y = p.y; r.zz = fe_sqr<Q>(p.z); r.zzz = fe_mul<Q>(r.zz, p.z); return r;
+// the same operations through the native radix-2^29 field (Fq only): in/out in arkworks words
+__global__ __launch_bounds__(256) void k_test_field29(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fq<2> x = fq_from_words(fe_load(a + 4 * (size_t)i));
+    Fq<2> y = b ? fq_from_words(fe_load(b + 4 * (size_t)i)) : fq_zero<2>();
+    Fe r;
+    switch (op) {
+        case 0: r = fq_to_words(fq_mul(x, y)); break;
+        case 1: r = fq_to_words(fq_add(x, y)); break;
+        case 2: r = fq_to_words(fq_sub<2>(x, y)); break;
+        case 3: r = fq_is_zero_modp(x) ? fe_zero() : fq_to_words(fq_inv(x)); break;
+        case 6: r = fq_to_words(fq_sqr(x)); break;
+        case 7: r = fq_to_words(fq_muls<4>(fq_muls<3>(fq_add(x, y)))); break;  // 12 (x + y), lazy chain
+        case 8: r = fq_to_words(fq_tighten(fq_sub_sub2(fq_muls<4>(x), y, x))); break;  // 2x - y
+        default: r = fq_to_words(x); break;                                            // round trip
+    }
+    fe_store(out + 4 * (size_t)i, r);
+}
+HALO_DEV bool aff_same(const AffN &a, const AffN &b) {
+    if (aff_is_inf(a) || aff_is_inf(b)) return aff_is_inf(a) && aff_is_inf(b);
+    return fq_eq_modp(a.x, b.x) && fq_eq_modp(a.y, b.y);
 }
 __global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Jac p = jac_load(a + 12 * (size_t)i);
-    Jac r;
+    JacN p = jac_from_words(a + 12 * (size_t)i);
+    uint64_t *o = out + 12 * (size_t)i;
     if (op == 0) {
-        Xyzz x = jac_to_xyzz(p);
-        xyzz_add(x, jac_to_xyzz(jac_load(b + 12 * (size_t)i)));
-        r = xyzz_to_jac(x);
+        XyzzN x = jac_to_xyzz(p);
+        xyzz_add(x, jac_to_xyzz(jac_from_words(b + 12 * (size_t)i)));
+        xyzz_store_jac_words(o, x);
     } else if (op == 1) {
-        Aff q = aff_load(b + 8 * (size_t)i);
-        Xyzz x = jac_to_xyzz(p);
+        AffN q = aff_from_words(b + 8 * (size_t)i);
+        XyzzN x = jac_to_xyzz(p);
         xyzz_madd(x, q);
-        Jac r1 = xyzz_to_jac(x);
-        Jac r2 = jac_madd(p, q);  // both mixed-add forms must agree; disagreement poisons the output
-        Aff a1 = jac_to_aff(r1), a2 = jac_to_aff(r2);
-        r = (fe_eq(a1.x, a2.x) && fe_eq(a1.y, a2.y)) ? r2 : jac_from_aff(Aff{fe_one<Q>(), fe_one<Q>()});
+        JacN r2 = jac_madd(p, q);  // both mixed-add forms must agree; disagreement poisons the output
+        JacN x1; x1.x = fq_widen<8>(fq_mul(x.x, fq_sqr(x.zz))); x1.y = fq_widen<8>(fq_mul(x.y, fq_sqr(x.zzz))); x1.z = fq_widen<4>(x.zzz);
+        if (xyzz_is_inf(x)) x1 = jac_inf();
+        if (aff_same(jac_to_aff(x1), jac_to_aff(r2))) jac_store_words(o, r2);
+        else { AffN bad; bad.x = fq_widen<2>(fq_one()); bad.y = bad.x; jac_store_words(o, jac_from_aff(bad)); }
     } else if (op == 2) {
-        Jac r1 = jac_dbl(p);
-        Jac r2 = xyzz_to_jac(xyzz_dbl(jac_to_xyzz(p)));
-        Aff a1 = jac_to_aff(r1), a2 = jac_to_aff(r2);
-        r = (fe_eq(a1.x, a2.x) && fe_eq(a1.y, a2.y)) ? r1 : jac_from_aff(Aff{fe_one<Q>(), fe_one<Q>()});
+        JacN r1 = jac_dbl(p);
+        XyzzN x = xyzz_dbl(jac_to_xyzz(p));
+        JacN x1; x1.x = fq_widen<8>(fq_mul(x.x, fq_sqr(x.zz))); x1.y = fq_widen<8>(fq_mul(x.y, fq_sqr(x.zzz))); x1.z = fq_widen<4>(x.zzz);
+        if (xyzz_is_inf(x)) x1 = jac_inf();
+        if (aff_same(jac_to_aff(r1), jac_to_aff(x1))) jac_store_words(o, r1);
+        else { AffN bad; bad.x = fq_widen<2>(fq_one()); bad.y = bad.x; jac_store_words(o, jac_from_aff(bad)); }
     } else {
         // p * scalar (Montgomery Fr), MSB-first double-and-add on the affine form of p
         Fe k = fe_from_mont<FrCfg>(fe_load(b + 4 * (size_t)i));
-        Aff pa = jac_to_aff(p);
-        Jac acc = jac_inf();
+        AffN pa = jac_to_aff(p);
+        JacN acc = jac_inf();
 #pragma unroll 1
         for (int limb = 7; limb >= 0; limb--) {
             uint32_t word = 0;
@@ -364,14 +397,14 @@ __global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, c
                 if ((word >> bit) & 1u) acc = jac_madd(acc, pa);
             }
         }
-        r = acc;
+        jac_store_words(o, acc);
     }
-    jac_store(out + 12 * (size_t)i, r);
 }
 
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (field == 0) HALO_LAUNCH(ctx, "k_test_field", k_test_field<FqCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+    if (field == 2) HALO_LAUNCH(ctx, "k_test_field29", k_test_field29, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+    else if (field == 0) HALO_LAUNCH(ctx, "k_test_field", k_test_field<FqCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
     else HALO_LAUNCH(ctx, "k_test_field", k_test_field<FrCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
@@ -383,10 +416,22 @@ int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_
     return HALO_OK;
 }
 
-int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint64_t *d_out) {
+int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     HALO_LAUNCH(ctx, "k_batch_to_affine", k_batch_to_affine, grid, block, 0, d_jac, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t *d_out) {
+    if (n == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_aff_to_native", k_aff_to_native, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_in, (uint32_t)n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out) {
+    if (n == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_native_to_aff", k_native_to_aff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_in, (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }
@@ -411,7 +456,7 @@ static const std::vector<uint64_t> &urs_table() {
     return tbl;
 }
 
-int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out) {
+int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
     const std::vector<uint64_t> &tbl = urs_table();
     std::vector<uint64_t> canon(4 * n);
@@ -420,15 +465,20 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint64_t *d_out)
         s.store(&canon[4 * i]);
     }
     uint64_t *d_tbl = nullptr, *d_canon = nullptr;
+    uint32_t *d_tbl_native = nullptr;
     HALO_HIP(hipMalloc(&d_tbl, tbl.size() * 8));
+    HALO_HIP(hipMalloc(&d_tbl_native, (size_t)1024 * AFF_WORDS * 4));
     HALO_HIP(hipMalloc(&d_canon, canon.size() * 8));
     HALO_HIP(hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HALO_HIP(hipMemcpyAsync(d_canon, canon.data(), canon.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = aff_words_to_native(ctx, d_tbl, 1024, d_tbl_native);
+    if (rc) return rc;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, d_tbl, reinterpret_cast<const uint32_t *>(d_canon), (uint32_t)n, d_out);
+    HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, d_tbl_native, reinterpret_cast<const uint32_t *>(d_canon), (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_tbl);
+    (void)hipFree(d_tbl_native);
     (void)hipFree(d_canon);
     return HALO_OK;
 }
@@ -452,21 +502,21 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
     // tasks <= non-empty buckets + entries / KMAX
     ws.cap_tasks = ws.cap_counts + ws.cap_sorted / KMAX + 1;
-    HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * 128));
+    HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_ntask, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_tblockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_biglist, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_meta, 64));
-    HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 32 * 8));
+    HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, (size_t)64 * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, (size_t)64 * 12 * 8));
     return HALO_OK;
 }
 void msm_workspace_free(halo_ctx *ctx) {
     MsmWorkspace &ws = ctx->ws;
-    uint64_t *p64[] = {ws.d_canon, ws.d_buckets, ws.d_seg, ws.d_winsum};
-    uint32_t *p32[] = {ws.d_counts, ws.d_starts, ws.d_cursor, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta};
+    uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
+    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_cursor, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta};
     for (auto p : p64) (void)hipFree(p);
     for (auto p : p32) (void)hipFree(p);
     if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
@@ -474,7 +524,7 @@ void msm_workspace_free(halo_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------------ driver
-int msm_run(halo_ctx *ctx, const uint64_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, host::Point *out) {
+int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, host::Point *out) {
     *out = host::Point::infinity();
     if (n == 0) return HALO_OK;
     MsmWorkspace &ws = ctx->ws;

@@ -78,7 +78,7 @@ static int pedersen_commit_dev(halo_ctx *ctx, const Fr *w, const uint64_t *d_ms,
 // pcdl::commit for a short host polynomial (acc.rs:153,195: two coefficients): same point, no launch
 static int commit_short_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, const Fr *w, Point *out) {
     std::vector<uint64_t> bases(8 * len);
-    int rc = download_words(ctx, bases.data(), ctx->d_bases, 8 * len);
+    int rc = halo_ctx_read_bases(ctx, 0, len, bases.data());
     if (rc) return rc;
     std::vector<Point> pts(len);
     std::vector<Fr> ks(len);

@@ -70,6 +70,34 @@ def test_field_ops(ctx16k):
                 assert got * x * rinv % mod == pm.MONT_R % mod  # got (*) x == one
 
 
+def test_native_radix29_field(ctx16k):
+    """The lazy 9 x 29-bit Fq of fq29.cuh against big-int arithmetic, through arkworks-form I/O."""
+    n = 4096
+    a, s = orc.rng_scalars(3, n)
+    b, _ = orc.rng_scalars(s, n)
+    mod = pm.P
+    A = [int.from_bytes(x.tobytes(), "little") % mod for x in a]
+    B = [int.from_bytes(x.tobytes(), "little") % mod for x in b]
+    edge = [0, 1, mod - 1, pm.MONT_R % mod, 2, mod - 2, (1 << 254) % mod, (1 << 29) - 1, 1 << 29, (1 << 232) + 5]
+    for i, e in enumerate(edge):
+        A[i] = e
+        B[(i + 3) % len(edge)] = e
+    tolimbs = lambda vals: np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+    am, bm = tolimbs(A), tolimbs(B)
+    rinv = pm.inv_mod(pm.MONT_R, mod)
+    ints = lambda arr: [int.from_bytes(x.tobytes(), "little") for x in arr]
+    assert ints(ctx16k.field_op(2, 9, am, bm)) == A                                              # round trip
+    assert ints(ctx16k.field_op(2, 0, am, bm)) == [x * y * rinv % mod for x, y in zip(A, B)]    # mul
+    assert ints(ctx16k.field_op(2, 6, am, bm)) == [x * x * rinv % mod for x in A]               # sqr
+    assert ints(ctx16k.field_op(2, 1, am, bm)) == [(x + y) % mod for x, y in zip(A, B)]
+    assert ints(ctx16k.field_op(2, 2, am, bm)) == [(x - y) % mod for x, y in zip(A, B)]
+    assert ints(ctx16k.field_op(2, 7, am, bm)) == [12 * (x + y) % mod for x, y in zip(A, B)]
+    assert ints(ctx16k.field_op(2, 8, am, bm)) == [(2 * x - y) % mod for x, y in zip(A, B)]
+    inv = ints(ctx16k.field_op(2, 3, am[:256], bm[:256]))
+    for x, got in zip(A[:256], inv):
+        assert got == (0 if x == 0 else pm.inv_mod(x, mod) * pm.MONT_R * pm.MONT_R % mod)
+
+
 def test_point_ops(ctx16k, urs4096):
     n = 512
     ks, s = orc.rng_scalars(77, n)
