@@ -58,14 +58,15 @@ MsmPlan msm_plan(size_t n, int forced_c);
 
 struct MsmWorkspace {
     size_t cap_n = 0;
-    uint64_t *d_canon = nullptr;     // n x 4 canonical scalars
+    uint64_t *d_canon = nullptr;     // u16 signed digits, layout [w][i]
+    uint32_t *d_hist = nullptr;      // per (window, chunk) bucket histograms / prefixes
     uint32_t *d_counts = nullptr;    // W*B
     uint32_t *d_starts = nullptr;    // W*B exclusive scan within 4096-entry blocks
     uint32_t *d_blockoff = nullptr;  // per 4096-entry block offset
-    uint32_t *d_cursor = nullptr;    // W*B
     uint32_t *d_sorted = nullptr;    // n*W entries: point index | sign << 31
     uint32_t *d_buckets = nullptr;   // one native XYZZ partial (40 words) per task
     uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
+    uint32_t *d_task_g = nullptr, *d_order = nullptr;  // per task: bucket | length bin << 24; tasks by decreasing length
     uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned

@@ -48,14 +48,17 @@ HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c
     return d;
 }
 
-__global__ __launch_bounds__(256) void k_msm_count(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int W,
-                                                   uint32_t B, uint64_t *__restrict__ canon, uint32_t *__restrict__ counts) {
+// Digits are stored once as u16: (|d| - 1) | sign << 15, 0xFFFF for a zero digit (|d| - 1 = 2^15 - 1
+// with the sign set cannot occur: negative digits have magnitude <= B - 1).  Layout [w][i].
+constexpr uint32_t DIGIT_NONE = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int W,
+                                                    uint32_t B, uint16_t *__restrict__ digits) {
     __shared__ uint32_t sw[256 * 9];
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Fe s = fe_load(scalars + 4 * (size_t)i);
-    if (mont) s = fe_from_mont<FrCfg>(s);
-    fe_store(canon + 4 * (size_t)i, s);
+    if (mont) s = fe_from_mont<FrCfg>(s);  // arkworks `into_bigint`
     uint32_t *my = sw + threadIdx.x * 9;
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
@@ -63,28 +66,63 @@ __global__ __launch_bounds__(256) void k_msm_count(const uint64_t *__restrict__ 
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
         Digit d = next_digit(my, w, c, B, carry);
-        if (d.mag) atomicAdd(&counts[(uint32_t)w * B + d.mag - 1], 1u);
+        digits[(size_t)w * n + i] = (uint16_t)(d.mag ? ((d.mag - 1) | (d.neg << 15)) : DIGIT_NONE);
     }
 }
 
-__global__ __launch_bounds__(256) void k_msm_scatter(const uint64_t *__restrict__ canon, uint32_t n, int c, int W, uint32_t B,
-                                                     const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
-                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t sw[256 * 9];
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Fe s = fe_load(canon + 4 * (size_t)i);
-    uint32_t *my = sw + threadIdx.x * 9;
-#pragma unroll
-    for (int k = 0; k < 8; k++) my[k] = s.v[k];
-    my[8] = 0;
-    uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
-        Digit d = next_digit(my, w, c, B, carry);
-        if (d.mag) {
-            uint32_t g = (uint32_t)w * B + d.mag - 1;
-            uint32_t pos = atomicAdd(&cursor[g], 1u);
-            sorted[starts[g] + blockoff[g >> 12] + pos] = i | (d.neg << 31);
+// Counting sort of one window's digits with the whole histogram in LDS (B <= 2^15 counters =
+// 128 KiB of the CU's 160 KiB).  Block (w, chunk) covers scalars [chunk*len, (chunk+1)*len).
+// hist layout [w][chunk][b] so that every global access is coalesced.
+__global__ __launch_bounds__(1024) void k_msm_hist(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
+                                                   uint32_t chunk_len, uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t lds[];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = 0;
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *dg = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        uint32_t d = dg[i];
+        if (d != DIGIT_NONE) atomicAdd(&lds[d & 0x7FFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = hist + ((size_t)w * nchunks + chunk) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = lds[b];
+}
+// per bucket: total over chunks -> counts[g]; hist[w][chunk][b] <- exclusive prefix over chunks
+__global__ __launch_bounds__(256) void k_msm_colsum(uint32_t *__restrict__ hist, uint32_t B, uint32_t nchunks, uint32_t total,
+                                                    uint32_t *__restrict__ counts) {
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    uint32_t w = g / B, b = g % B;
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        uint32_t *p = hist + ((size_t)w * nchunks + ch) * B + b;
+        uint32_t t = *p;
+        *p = run;
+        run += t;
+    }
+    counts[g] = run;
+}
+__global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
+                                                      uint32_t chunk_len, const uint32_t *__restrict__ hist,
+                                                      const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
+                                                      uint32_t *__restrict__ sorted) {
+    extern __shared__ uint32_t lds[];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    const uint32_t *pre = hist + ((size_t)w * nchunks + chunk) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) {
+        uint32_t g = w * B + b;
+        lds[b] = starts[g] + blockoff[g >> 12] + pre[b];
+    }
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *dg = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        uint32_t d = dg[i];
+        if (d != DIGIT_NONE) {
+            uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
+            sorted[pos] = i | ((d >> 15) << 31);
         }
     }
 }
@@ -157,23 +195,77 @@ __global__ __launch_bounds__(256) void k_msm_task_meta(const uint32_t *__restric
     uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     if (g == total - 1) meta[0] = scan_at(toff, tblockoff, g) + ntask[g];
-    if (ntask[g] > 1) biglist[atomicAdd(&meta[1], 1u)] = g;
+    // multi-task buckets: 2..8 tasks are folded by one lane each, more by a wave each
+    uint32_t nt = ntask[g];
+    if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
+    else if (nt > 1) biglist[total - 1 - atomicAdd(&meta[140], 1u)] = g;  // small list grows down from the end
+}
+
+// Tasks are processed in order of decreasing length so that the 64 lanes of a wave run chains of
+// (almost) equal length: bucket sizes are Poisson distributed and a wave otherwise waits for its
+// longest lane (~68 % lane efficiency at 32 points per bucket).  Counting sort over 65 length bins,
+// aggregated per block in LDS so that only <= 65 global atomics per block are issued.
+// meta[2 .. 2+65) = bin totals, meta[70 .. 70+65) = bin cursors.
+HALO_DEV void task_locate(const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
+                          const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t t, uint32_t &g, uint32_t &len) {
+    uint32_t lo = 0, hi = total_buckets - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (scan_at(toff, tblockoff, mid) <= t) lo = mid; else hi = mid - 1;
+    }
+    g = lo;
+    uint32_t first = (t - scan_at(toff, tblockoff, g)) * KMAX;
+    len = counts[g] - first;
+    if (len > KMAX) len = KMAX;
+}
+__global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
+                                                       const uint32_t *__restrict__ counts, uint32_t total_buckets,
+                                                       uint32_t *__restrict__ meta, uint32_t *__restrict__ task_g) {
+    __shared__ uint32_t bins[KMAX + 1];
+    if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < meta[0]) {
+        uint32_t g, len;
+        task_locate(toff, tblockoff, counts, total_buckets, t, g, len);
+        task_g[t] = g | ((KMAX - len) << 24);  // bucket id (< 2^20) and bin = 64 - len
+        atomicAdd(&bins[KMAX - len], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= KMAX && bins[threadIdx.x]) atomicAdd(&meta[2 + threadIdx.x], bins[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restrict__ task_g, uint32_t *__restrict__ meta,
+                                                        uint32_t *__restrict__ order) {
+    __shared__ uint32_t bins[KMAX + 1], base[KMAX + 1];
+    if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    bool live = t < meta[0];
+    uint32_t bin = 0, rank = 0;
+    if (live) {
+        bin = task_g[t] >> 24;
+        rank = atomicAdd(&bins[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= KMAX) {
+        uint32_t start = 0;  // exclusive prefix of the global bin totals (65 values)
+        for (uint32_t k = 0; k < threadIdx.x; k++) start += meta[2 + k];
+        base[threadIdx.x] = start + (bins[threadIdx.x] ? atomicAdd(&meta[70 + threadIdx.x], bins[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (live) order[base[bin] + rank] = t;
 }
 
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
                                                         const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
                                                         const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                        uint32_t total_buckets, uint32_t *__restrict__ partial) {
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= meta[0]) return;
-    // bucket of task t: last g with toff(g) <= t (ties are empty buckets, which sort before their non-empty successor)
-    uint32_t lo = 0, hi = total_buckets - 1;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi + 1) >> 1;
-        if (scan_at(toff, tblockoff, mid) <= t) lo = mid; else hi = mid - 1;
-    }
-    uint32_t g = lo;
+                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_g,
+                                                        uint32_t *__restrict__ partial) {
+    uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    if (tid >= meta[0]) return;
+    uint32_t t = order[tid];
+    uint32_t g = task_g[t] & 0xFFFFFFu;
     uint32_t first = (t - scan_at(toff, tblockoff, g)) * KMAX;
     uint32_t cnt = counts[g] - first;
     if (cnt > KMAX) cnt = KMAX;
@@ -188,7 +280,24 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     xyzz_store(partial + XYZZ_WORDS * (size_t)t, acc);
 }
 
-// one wave per multi-task bucket (grid-stride over biglist): partial[toff(g)] <- sum of its partials
+// one lane per bucket with 2..8 tasks (grid-stride over the tail of biglist)
+__global__ __launch_bounds__(256) void k_msm_combine_small(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                                                          const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
+                                                          const uint32_t *__restrict__ biglist, uint32_t total,
+                                                          uint32_t *__restrict__ partial) {
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < meta[140]; b += gridDim.x * 256) {
+        uint32_t g = biglist[total - 1 - b];
+        uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
+        XyzzN acc = xyzz_load(partial + XYZZ_WORDS * (size_t)t0);
+#pragma unroll 1
+        for (uint32_t j = 1; j < nt; j++) {
+            XyzzN q = xyzz_load(partial + XYZZ_WORDS * (size_t)(t0 + j));
+            xyzz_add(acc, q);
+        }
+        xyzz_store(partial + XYZZ_WORDS * (size_t)t0, acc);
+    }
+}
+// one wave per bucket with more than 8 tasks (grid-stride over biglist): partial[toff(g)] <- sum of its partials
 __global__ __launch_bounds__(64) void k_msm_combine_big(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
                                                         const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
                                                         const uint32_t *__restrict__ biglist, uint32_t *__restrict__ partial) {
@@ -494,10 +603,13 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     size_t srt = n >= 4096 ? n * 32 : n * 64;
     ws.cap_counts = max_counts();
     ws.cap_sorted = srt;
-    HALO_HIP(hipMalloc(&ws.d_canon, n * 32));
+    // the LDS histograms need up to 128 KiB of dynamic LDS per block (160 KiB per CU on gfx950)
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
+    HALO_HIP(hipMalloc(&ws.d_hist, (size_t)256 * 32768 * 4 + ws.cap_counts * 4));  // [w][chunk][b], W * nchunks <= 256
     HALO_HIP(hipMalloc(&ws.d_counts, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_starts, ws.cap_counts * 4));
-    HALO_HIP(hipMalloc(&ws.d_cursor, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
     // tasks <= non-empty buckets + entries / KMAX
@@ -507,7 +619,9 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_tblockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_biglist, ws.cap_counts * 4));
-    HALO_HIP(hipMalloc(&ws.d_meta, 64));
+    HALO_HIP(hipMalloc(&ws.d_meta, 1024));
+    HALO_HIP(hipMalloc(&ws.d_task_g, ws.cap_tasks * 4));
+    HALO_HIP(hipMalloc(&ws.d_order, ws.cap_tasks * 4));
     HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, (size_t)64 * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, (size_t)64 * 12 * 8));
@@ -516,7 +630,7 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
 void msm_workspace_free(halo_ctx *ctx) {
     MsmWorkspace &ws = ctx->ws;
     uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
-    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_cursor, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta};
+    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
     for (auto p : p64) (void)hipFree(p);
     for (auto p : p32) (void)hipFree(p);
     if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
@@ -533,18 +647,26 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
     size_t total = (size_t)p.W * p.B;
     if (total > ws.cap_counts || n * (size_t)p.W > ws.cap_sorted) { set_error("msm: window plan exceeds workspace"); return HALO_E_ARG; }
     hipStream_t s = ctx->stream;
-    HALO_HIP(hipMemsetAsync(ws.d_counts, 0, total * 4, s));
-    HALO_HIP(hipMemsetAsync(ws.d_cursor, 0, total * 4, s));
     dim3 gridn((unsigned)((n + 255) / 256)), b256(256);
-    HALO_LAUNCH(ctx, "k_msm_count", k_msm_count, gridn, b256, 0, d_scalars, mont ? 1 : 0, (uint32_t)n, p.c, p.W, p.B, ws.d_canon,
+    uint16_t *d_digits = reinterpret_cast<uint16_t *>(ws.d_canon);  // n * W * 2 bytes
+    HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, gridn, b256, 0, d_scalars, mont ? 1 : 0, (uint32_t)n, p.c, p.W, p.B, d_digits);
+    // one block per (window, chunk): about one block per CU, chunks of at least 1024 scalars
+    uint32_t nchunks = 256u / (uint32_t)p.W;
+    if (nchunks < 1) nchunks = 1;
+    while (nchunks > 1 && (n + nchunks - 1) / nchunks < 1024) nchunks--;
+    uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
+    dim3 gridh((unsigned)(p.W * nchunks)), b1024(1024);
+    size_t lds_bytes = (size_t)p.B * 4;
+    HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist);
+    HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
                 ws.d_counts);
     uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
-    HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridn, b256, 0, ws.d_canon, (uint32_t)n, p.c, p.W, p.B, ws.d_starts, ws.d_blockoff,
-                ws.d_cursor, ws.d_sorted);
+    HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
+                ws.d_starts, ws.d_blockoff, ws.d_sorted);
     dim3 gridb((unsigned)((total + 255) / 256));
-    HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 64, s));
+    HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
     HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, ws.d_ntask);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
@@ -552,8 +674,14 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
                 ws.d_biglist);
     size_t max_tasks = total + n * (size_t)p.W / KMAX + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, dim3((unsigned)((max_tasks + 255) / 256)), b256, 0, d_bases, ws.d_sorted,
-                ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff, ws.d_tblockoff, ws.d_meta, (uint32_t)total, ws.d_buckets);
+    dim3 gridt((unsigned)((max_tasks + 255) / 256));
+    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, ws.d_meta,
+                ws.d_task_g);
+    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
+                ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_combine_small", k_msm_combine_small, dim3(512), b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
+                ws.d_biglist, (uint32_t)total, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine_big", k_msm_combine_big, dim3(1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
                 ws.d_biglist, ws.d_buckets);
     uint32_t L, nseg;
