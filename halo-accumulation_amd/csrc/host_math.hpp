@@ -256,6 +256,111 @@ inline Point small_msm(const std::vector<Point> &pts, const std::vector<Fr> &ks_
     return acc;
 }
 
+// ------------------------------------------------------------------ GLV split for the uniform-scalar fold
+// Pallas has the endomorphism phi(x, y) = (beta x, y) = [lambda](x, y), beta^3 = 1 in Fq,
+// lambda^3 = 1 in Fr.  xi = k1 + k2 lambda with |k1|, |k2| < 2^128 (Babai rounding on the short
+// basis (a1, -b1n), (a2, b2)); because P + phi P + phi^2 P = 0 the signs can always be moved so
+// that xi P = s1 T1 + s2 T2 with s1, s2 >= 0 and T1, T2, T1 + T2 each of the form
+// (beta^e x, +-y): a 128-step joint ladder whose three table entries cost two multiplications.
+struct GlvSplit {
+    uint32_t s1[5], s2[5];  // non-negative scalars, < 2^130, little-endian 32-bit words
+    int e[3];               // power of beta for T1, T2, T3 = T1 + T2
+    int neg12;              // 1: T1, T2 carry -y and T3 carries +y; 0: the opposite
+    int nbits;              // max bit length of s1, s2
+};
+namespace glv_detail {
+inline void mul_limbs(const u64 *a, int na, const u64 *b, int nb, u64 *out /* na + nb */) {
+    for (int i = 0; i < na + nb; ++i) out[i] = 0;
+    for (int i = 0; i < na; ++i) {
+        u64 carry = 0;
+        for (int j = 0; j < nb; ++j) {
+            u128 t = (u128)a[i] * b[j] + out[i + j] + carry;
+            out[i + j] = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        out[i + nb] = carry;
+    }
+}
+// (k * g + 2^383) >> 384 for 4-limb k and 5-limb g -> 3 limbs
+inline void round_shift(const u64 k[4], const u64 g[5], u64 c[3]) {
+    u64 prod[9];
+    mul_limbs(k, 4, g, 5, prod);
+    u64 carry = 1ULL << 63;  // + 2^383: bit 63 of limb 5
+    for (int i = 5; i < 9 && carry; ++i) {
+        u64 t = prod[i] + carry;
+        carry = t < prod[i] ? 1 : 0;
+        prod[i] = t;
+    }
+    c[0] = prod[6]; c[1] = prod[7]; c[2] = prod[8];
+}
+inline void sub256(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - b[i] - borrow; r[i] = (u64)d; borrow = (u64)(d >> 64) & 1; }
+}
+inline void add256(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 carry = 0;
+    for (int i = 0; i < 4; ++i) { u128 t = (u128)a[i] + b[i] + carry; r[i] = (u64)t; carry = (u64)(t >> 64); }
+}
+inline void mul_lo256(const u64 c[3], const u64 v[2], u64 out[4]) {
+    u64 full[5];
+    mul_limbs(c, 3, v, 2, full);
+    for (int i = 0; i < 4; ++i) out[i] = full[i];
+}
+inline bool negative(const u64 v[4]) { return (v[3] >> 63) != 0; }
+inline void negate(u64 v[4]) { u64 z[4] = {0, 0, 0, 0}; sub256(v, z, v); }
+}  // namespace glv_detail
+
+inline GlvSplit glv_split(const Fr &xi_mont) {
+    using namespace glv_detail;
+    static const u64 G1[5] = {0x111f686111afc293ULL, 0xc35fbd4d086862e0ULL, 0x31f0256800000002ULL, 0x4f34e8b2066389a4ULL, 0x2ULL};
+    static const u64 G2[5] = {0x4a95a2d972171db4ULL, 0x61afdea68480fa55ULL, 0x32c49e4bffffffffULL, 0x279a745902a2654eULL, 0x1ULL};
+    static const u64 A1[2] = {0x7fcae1c700000001ULL, 0x49e69d1640f04915ULL};
+    static const u64 B1N[2] = {0x8cb1279300000000ULL, 0x49e69d1640a89953ULL};  // b1 = -B1N
+    static const u64 A2[2] = {0x8cb1279300000000ULL, 0x49e69d1640a89953ULL};
+    static const u64 B2[2] = {0x0c7c095a00000001ULL, 0x93cd3a2c8198e269ULL};
+    Fr k = xi_mont.from_mont();
+    u64 c1[3], c2[3], t[4], k1[4], k2[4];
+    round_shift(k.l, G1, c1);
+    round_shift(k.l, G2, c2);
+    // k1 = k - c1 a1 - c2 a2 ; k2 = c1 b1n - c2 b2   (mod 2^256, small signed results)
+    mul_lo256(c1, A1, t); sub256(k1, k.l, t);
+    mul_lo256(c2, A2, t); sub256(k1, k1, t);
+    mul_lo256(c1, B1N, k2);
+    mul_lo256(c2, B2, t); sub256(k2, k2, t);
+    bool n1 = negative(k1), n2 = negative(k2);
+    if (n1) negate(k1);
+    if (n2) negate(k2);
+    u64 s1[4], s2[4];
+    GlvSplit r;
+    if (!n1 && !n2) {        // k1 P + k2 phi P
+        std::memcpy(s1, k1, 32); std::memcpy(s2, k2, 32);
+        r.e[0] = 0; r.e[1] = 1; r.e[2] = 2; r.neg12 = 0;
+    } else if (!n1 && n2) {  // (k1 + |k2|) P + |k2| phi^2 P
+        add256(s1, k1, k2); std::memcpy(s2, k2, 32);
+        r.e[0] = 0; r.e[1] = 2; r.e[2] = 1; r.neg12 = 0;
+    } else if (n1 && !n2) {  // (|k1| + k2) phi P + |k1| phi^2 P
+        add256(s1, k1, k2); std::memcpy(s2, k1, 32);
+        r.e[0] = 1; r.e[1] = 2; r.e[2] = 0; r.neg12 = 0;
+    } else {                 // |k1| (-P) + |k2| (-phi P)
+        std::memcpy(s1, k1, 32); std::memcpy(s2, k2, 32);
+        r.e[0] = 0; r.e[1] = 1; r.e[2] = 2; r.neg12 = 1;
+    }
+    int nbits = 0;
+    for (int i = 0; i < 5; ++i) {
+        int limb = i / 2, half = i % 2;
+        r.s1[i] = limb < 4 ? (uint32_t)(s1[limb] >> (32 * half)) : 0;
+        r.s2[i] = limb < 4 ? (uint32_t)(s2[limb] >> (32 * half)) : 0;
+        uint32_t both = r.s1[i] | r.s2[i];
+        if (both) {
+            int top = 31;
+            while (!((both >> top) & 1)) --top;
+            nbits = 32 * i + top + 1;
+        }
+    }
+    r.nbits = nbits;
+    return r;
+}
+
 // ------------------------------------------------------------------ SHA3-256 (FIPS 202)
 class Sha3_256 {
    public:

@@ -24,21 +24,63 @@ HALO_DEV Fe from_arg(const FeArg &a) {
 }
 
 // ------------------------------------------------------------------ K3: G'[j] = G[j] + xi * G[j+m]
-__global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, uint32_t m, FeArg xi_canon) {
+// xi is one scalar for the whole launch, split on the host as xi = s1 [T1] + s2 [T2] (host_math.hpp
+// glv_split): a joint double-and-add over max(|s1|, |s2|) <= 130 bits whose table
+// T1, T2, T3 = T1 + T2 is (beta^e x, +-y) -- two multiplications per point.  Every branch below
+// depends only on kernel arguments, so the 64 lanes of a wave never diverge.
+struct GlvArg {
+    uint32_t s1[5], s2[5];
+    int e0, e1, e2, neg12, nbits;
+};
+HALO_DEV Fq<2> fq_const(const uint32_t (&c)[9]) {
+    Fq<2> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c[i];
+    return r;
+}
+HALO_DEV Fq<2> pick3(int e, const Fq<2> &a, const Fq<2> &b, const Fq<2> &c) {
+    Fq<2> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = e == 0 ? a.v[i] : (e == 1 ? b.v[i] : c.v[i]);
+    return r;
+}
+__global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, uint32_t m, GlvArg a) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     AffN hi = aff_load(G + AFF_WORDS * (size_t)(j + m));
     AffN lo = aff_load(G + AFF_WORDS * (size_t)j);
+    if (aff_is_inf(hi)) return;  // G[j] + xi * infinity = G[j]
+    constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
+    constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
+    Fq<2> x0 = hi.x, x1 = fq_mul(hi.x, fq_const(BETA)), x2 = fq_mul(hi.x, fq_const(BETA2));
+    Fq<2> yp = hi.y, yn = fq_neg<2>(hi.y);
+    AffN T1, T2, T3;
+    T1.x = pick3(a.e0, x0, x1, x2);
+    T2.x = pick3(a.e1, x0, x1, x2);
+    T3.x = pick3(a.e2, x0, x1, x2);
+    T1.y = pick3(a.neg12, yp, yn, yn);
+    T2.y = T1.y;
+    T3.y = pick3(a.neg12, yn, yp, yp);
     JacN acc = jac_inf();
+    int top = a.nbits - 1;
 #pragma unroll 1
-    for (int limb = 7; limb >= 0; limb--) {
-        uint32_t word = 0;
+    for (int limb = top >> 5; limb >= 0; limb--) {
+        uint32_t w1 = 0, w2 = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) word = (q == limb) ? xi_canon.v[q] : word;
+        for (int q = 0; q < 5; q++) {
+            w1 = (q == limb) ? a.s1[q] : w1;
+            w2 = (q == limb) ? a.s2[q] : w2;
+        }
 #pragma unroll 1
-        for (int bit = 31; bit >= 0; bit--) {
+        for (int bit = (limb == (top >> 5)) ? (top & 31) : 31; bit >= 0; bit--) {
             acc = jac_dbl(acc);
-            if ((word >> bit) & 1u) acc = jac_madd(acc, hi);  // wave-uniform branch
+            uint32_t sel = ((w1 >> bit) & 1u) | (((w2 >> bit) & 1u) << 1);
+            if (sel) {  // wave-uniform
+                AffN t;
+                t.x = pick3((int)sel - 1, T1.x, T2.x, T3.x);
+                t.y = pick3((int)sel - 1, T1.y, T2.y, T3.y);
+                acc = jac_madd(acc, t);
+            }
         }
     }
     acc = jac_madd(acc, lo);
@@ -237,8 +279,11 @@ __global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const ui
 // ================================================================== host launchers
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
-    FeArg xi = to_arg(xi_mont.from_mont());
-    HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, xi);
+    host::GlvSplit sp = host::glv_split(xi_mont);
+    GlvArg a;
+    for (int i = 0; i < 5; ++i) { a.s1[i] = sp.s1[i]; a.s2[i] = sp.s2[i]; }
+    a.e0 = sp.e[0]; a.e1 = sp.e[1]; a.e2 = sp.e[2]; a.neg12 = sp.neg12; a.nbits = sp.nbits;
+    HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, a);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }
