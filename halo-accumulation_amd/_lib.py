@@ -49,6 +49,8 @@ _SIGS = {
     "halo_public_points": (C.c_int, [u64p, u64p]),
     "halo_msm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_int, u64p]),
     "halo_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, u64p]),
+    "halo_msm_dev_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "halo_msm_dev_end": (C.c_int, [C.c_void_p, C.c_int, u64p]),
     "halo_msm_points": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "halo_scalar_dot": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "halo_powers": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
@@ -169,6 +171,14 @@ class Context:
     def msm_dev(self, dptr: int, n: int, off=0, mont=True):
         out = np.zeros(12, dtype=np.uint64)
         check(self.lib.halo_msm_dev(self.h, off, n, C.c_void_p(dptr), int(mont), ptr(out)))
+        return out
+
+    def msm_dev_begin(self, slot: int, dptr: int, n: int, off=0, mont=True):
+        check(self.lib.halo_msm_dev_begin(self.h, slot, off, n, C.c_void_p(dptr), int(mont)))
+
+    def msm_dev_end(self, slot: int):
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm_dev_end(self.h, slot, ptr(out)))
         return out
 
     def msm_points(self, pts_jac, scalars):

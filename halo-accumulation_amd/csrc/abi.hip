@@ -62,7 +62,9 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipSetDevice(device));
     ctx->device = device;
     ctx->n = n;
-    HALO_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
+    HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[1], hipStreamNonBlocking));
+    ctx->stream = ctx->streams[0];
     HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 80));
     size_t tn = n < 64 ? 64 : n;
     ctx->tmp_words = tn * 12;
@@ -70,7 +72,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 10 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
-    return msm_workspace_alloc(ctx, n);
+    return msm_workspace_alloc(ctx, n, 0);
 }
 
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
@@ -161,7 +163,7 @@ int halo_ctx_create_urs(int device, uint64_t first_index, size_t n, halo_ctx **o
 void halo_ctx_destroy(halo_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto st : ctx->streams) if (st) (void)hipStreamSynchronize(st);
     ctx->prof.collect();
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     msm_workspace_free(ctx);
@@ -172,7 +174,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_poly);
     (void)hipFree(ctx->d_poly2);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -201,6 +203,21 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
     if (off + n > ctx->n || !out || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     host::Point r;
     int rc = msm_run(ctx, ctx->d_bases + 20 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n, &r);
+    if (rc) return rc;
+    r.store_normalized(out);
+    return HALO_OK;
+}
+
+int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int mont) {
+    HALO_CTX(ctx);
+    if (off + n > ctx->n || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    return msm_enqueue(ctx, slot, ctx->d_bases + 20 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n);
+}
+int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
+    HALO_CTX(ctx);
+    if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
+    host::Point r;
+    int rc = msm_finish(ctx, slot, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -402,7 +419,8 @@ size_t halo_ipa_len(const halo_ipa *st) { return st ? st->m : 0; }
 // ------------------------------------------------------------------ measurement hooks
 int halo_prof_enable(halo_ctx *ctx, int on) {
     HALO_CTX(ctx);
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->streams[0]));
+    HALO_HIP(hipStreamSynchronize(ctx->streams[1]));
     ctx->prof.collect();
     ctx->prof.on = on != 0;
     ctx->prof.dominant_only = on == 2;
@@ -410,7 +428,8 @@ int halo_prof_enable(halo_ctx *ctx, int on) {
 }
 int halo_prof_reset(halo_ctx *ctx) {
     HALO_CTX(ctx);
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->streams[0]));
+    HALO_HIP(hipStreamSynchronize(ctx->streams[1]));
     ctx->prof.collect();
     for (auto &e : ctx->prof.entries) { e.total_ms = 0; e.launches = 0; }
     return HALO_OK;

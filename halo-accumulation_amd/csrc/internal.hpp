@@ -71,16 +71,19 @@ struct MsmWorkspace {
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
     size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0;
+    MsmPlan plan{};          // plan of the MSM in flight on this slot
+    bool in_flight = false;
 };
 
 }  // namespace halo
 
 struct halo_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
+    hipStream_t streams[2] = {nullptr, nullptr};
     size_t n = 0;
     uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.cuh AffN)
-    halo::MsmWorkspace ws;
+    halo::MsmWorkspace wss[2];         // two slots so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
     // scratch for host-pointer entry points
@@ -102,8 +105,11 @@ struct halo_ipa {
 namespace halo {
 
 // ---- msm.hip
-int msm_workspace_alloc(halo_ctx *ctx, size_t n);
+int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);
 void msm_workspace_free(halo_ctx *ctx);
+// asynchronous halves of msm_run on workspace/stream `slot`
+int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n);
+int msm_finish(halo_ctx *ctx, int slot, host::Point *out);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
 // bases: native affine table (20 words per point)
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);

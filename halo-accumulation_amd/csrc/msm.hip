@@ -595,8 +595,8 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out)
 // ------------------------------------------------------------------------------ workspace
 static size_t max_counts() { return (size_t)16 * 32768; }  // c = 16 is the largest W*B over c in [4, 16]
 
-int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
-    MsmWorkspace &ws = ctx->ws;
+int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
+    MsmWorkspace &ws = ctx->wss[slot];
     if (n < 64) n = 64;
     ws.cap_n = n;
     // sorted entries: n * W; the automatic plan has W <= 32 for n >= 4096 (c >= 8) and W <= 64 below
@@ -628,20 +628,43 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n) {
     return HALO_OK;
 }
 void msm_workspace_free(halo_ctx *ctx) {
-    MsmWorkspace &ws = ctx->ws;
-    uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
-    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
-    for (auto p : p64) (void)hipFree(p);
-    for (auto p : p32) (void)hipFree(p);
-    if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
-    ws = MsmWorkspace();
+    for (int slot = 0; slot < 2; ++slot) {
+        MsmWorkspace &ws = ctx->wss[slot];
+        uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
+        uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff,
+                           ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
+        for (auto p : p64) (void)hipFree(p);
+        for (auto p : p32) (void)hipFree(p);
+        if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
+        ws = MsmWorkspace();
+    }
 }
 
 // ------------------------------------------------------------------------------ driver
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, host::Point *out) {
-    *out = host::Point::infinity();
-    if (n == 0) return HALO_OK;
-    MsmWorkspace &ws = ctx->ws;
+    int rc = msm_enqueue(ctx, 0, d_bases, d_scalars, mont, n);
+    if (rc) return rc;
+    return msm_finish(ctx, 0, out);
+}
+
+struct StreamGuard {  // the launch macro uses ctx->stream
+    halo_ctx *ctx;
+    hipStream_t saved;
+    StreamGuard(halo_ctx *c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+    ~StreamGuard() { ctx->stream = saved; }
+};
+
+int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
+    if (slot < 0 || slot > 1) { set_error("msm: slot must be 0 or 1"); return HALO_E_ARG; }
+    if (!ctx->wss[slot].d_counts) {
+        int rc = msm_workspace_alloc(ctx, ctx->wss[0].cap_n, slot);
+        if (rc) return rc;
+    }
+    MsmWorkspace &ws = ctx->wss[slot];
+    if (ws.in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    ws.plan = MsmPlan{0, 0, 0};
+    if (n == 0) { ws.in_flight = true; return HALO_OK; }
+    StreamGuard guard(ctx, ctx->streams[slot]);
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
     MsmPlan p = msm_plan(n, ctx->window_bits);
     size_t total = (size_t)p.W * p.B;
@@ -694,8 +717,20 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
     HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)p.W), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)p.W * 96, hipMemcpyDeviceToHost, s));
-    HALO_HIP(hipStreamSynchronize(s));
-    if (ctx->prof.on) ctx->prof.collect();
+    ws.plan = p;
+    ws.in_flight = true;
+    return HALO_OK;
+}
+
+int msm_finish(halo_ctx *ctx, int slot, host::Point *out) {
+    *out = host::Point::infinity();
+    if (slot < 0 || slot > 1 || !ctx->wss[slot].in_flight) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
+    MsmWorkspace &ws = ctx->wss[slot];
+    ws.in_flight = false;
+    MsmPlan p = ws.plan;
+    if (p.W == 0) return HALO_OK;  // n == 0
+    HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
+    if (ctx->prof.on && !ctx->wss[slot ^ 1].in_flight) ctx->prof.collect();
     host::Point acc = host::Point::infinity();
     for (int w = p.W - 1; w >= 0; --w) {
         if (!acc.is_inf())
