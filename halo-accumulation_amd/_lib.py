@@ -83,6 +83,7 @@ _SIGS = {
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
+    "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
 }
@@ -251,6 +252,9 @@ class Context:
             check(self.lib.halo_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def set_ipa_switch(self, size):
+        check(self.lib.halo_set_ipa_switch(self.h, size))
 
     def set_window_bits(self, c):
         check(self.lib.halo_set_window_bits(self.h, c))

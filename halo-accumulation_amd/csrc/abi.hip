@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "internal.hpp"
 
@@ -99,12 +100,27 @@ int download_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t wor
 }
 
 
+// Key size at which the IPA stops folding G and switches to MSMs over the fixed key (ipa.hip).
+#define kNoFoldSize (ctx->nofold_size)
+static int ipa_enter_nofold(halo_ipa *st) {
+    halo_ctx *ctx = st->ctx;
+    st->nofold = true;
+    st->M = st->m;
+    st->s_len = 1;
+    uint64_t *one = ctx->h_pinned + 200;
+    host::Fr::one().store(one);
+    HALO_HIP(hipMemcpyAsync(st->d_s, one, 32, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    return HALO_OK;
+}
+
 int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out) {
     halo_ipa *st = new (std::nothrow) halo_ipa();
     if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
     st->ctx = ctx;
     st->n = st->m = n;
     int rc = HALO_OK;
+    if (hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) { delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
     do {
         if (hipMalloc(&st->d_G, n * 80) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
             hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
@@ -113,6 +129,13 @@ int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, cons
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
         }
         rc = fr_powers(ctx, z, n, st->d_z);
+        if (rc) break;
+        size_t M = n < kNoFoldSize ? n : kNoFoldSize;
+        if (hipMalloc(&st->d_s, M * 32) != hipSuccess || hipMalloc(&st->d_s2, M * 32) != hipSuccess ||
+            hipMalloc(&st->d_FL, M * 32) != hipSuccess || hipMalloc(&st->d_FR, M * 32) != hipSuccess) {
+            set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break;
+        }
+        if (n <= kNoFoldSize) rc = ipa_enter_nofold(st);
     } while (0);
     if (rc) { halo_ipa_destroy(st); return rc; }
     *out = st;
@@ -365,10 +388,28 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     int rc = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
     if (rc) return rc;
     host::Point Hp = host::Point::load(H_prime), Lp, Rp;
-    rc = msm_run(ctx, st->d_G, st->d_c + 4 * m, true, m, &Lp);  // <c_r, G_l>
+    // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; slot 1's stream first waits
+    // for everything queued on stream 0 (the previous round's folds)
+    HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
+    HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
+    if (st->nofold) {
+        rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
+        if (rc) return rc;
+        HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
+        HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
+        rc = msm_enqueue(ctx, 0, st->d_G, st->d_FL, true, st->M);
+        if (rc) return rc;
+        rc = msm_enqueue(ctx, 1, st->d_G, st->d_FR, true, st->M);
+    } else {
+        rc = msm_enqueue(ctx, 0, st->d_G, st->d_c + 4 * m, true, m);
+        if (rc) return rc;
+        rc = msm_enqueue(ctx, 1, st->d_G + 20 * m, st->d_c, true, m);
+    }
+    if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
+    rc = msm_finish(ctx, 0, &Lp);
+    int rc2 = msm_finish(ctx, 1, &Rp);
     if (rc) return rc;
-    rc = msm_run(ctx, st->d_G + 20 * m, st->d_c, true, m, &Rp);  // <c_l, G_r>
-    if (rc) return rc;
+    if (rc2) return rc2;
     (Lp + Hp.mul(dots[0])).store_normalized(L);
     (Rp + Hp.mul(dots[1])).store_normalized(R);
     return HALO_OK;
@@ -381,11 +422,18 @@ int halo_ipa_round_fold(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_in
     if (st->m < 2) { set_error("ipa_round_fold: no rounds left"); return HALO_E_ARG; }
     size_t m = st->m / 2;
     host::Fr x = host::Fr::load(xi), xinv = host::Fr::load(xi_inv);
-    int rc = ipa_fold_points(ctx, st->d_G, m, x);
+    int rc;
+    if (st->nofold) {
+        rc = nofold_s_update(ctx, st->d_s, st->s_len, x, st->d_s2);
+        if (!rc) { std::swap(st->d_s, st->d_s2); st->s_len *= 2; }
+    } else {
+        rc = ipa_fold_points(ctx, st->d_G, m, x);
+    }
     if (!rc) rc = ipa_fold_scalars(ctx, st->d_c, st->d_z, m, x, xinv);
     if (rc) return rc;
     st->m = m;
-    return HALO_OK;
+    if (!st->nofold && m <= kNoFoldSize && m > 1) rc = ipa_enter_nofold(st);
+    return rc;
 }
 
 int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
@@ -393,8 +441,19 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     halo_ctx *ctx = st->ctx;
     HALO_CTX(ctx);
     if (st->m != 1) { set_error("ipa_finish: rounds remaining"); return HALO_E_ARG; }
+    int rc;
+    if (st->nofold && st->M > 1) {
+        // U = G_final[0] = sum_t s[t] * G0[t]
+        host::Point Up;
+        rc = msm_run(ctx, st->d_G, st->d_s, true, st->M, &Up);
+        if (!rc) rc = download(ctx, c, st->d_c, 4);
+        if (rc) return rc;
+        if (ctx->prof.on) ctx->prof.collect();
+        Up.store_normalized(U);
+        return HALO_OK;
+    }
     uint64_t g[8];
-    int rc = aff_native_to_words(ctx, st->d_G, 1, ctx->d_tmp_a);
+    rc = aff_native_to_words(ctx, st->d_G, 1, ctx->d_tmp_a);
     if (!rc) rc = download(ctx, g, ctx->d_tmp_a, 8);
     if (!rc) rc = download(ctx, c, st->d_c, 4);
     if (rc) return rc;
@@ -409,9 +468,12 @@ void halo_ipa_destroy(halo_ipa *st) {
         (void)hipSetDevice(st->ctx->device);
         (void)hipStreamSynchronize(st->ctx->stream);
     }
+    if (st->ctx) (void)hipStreamSynchronize(st->ctx->streams[1]);
     (void)hipFree(st->d_G);
     (void)hipFree(st->d_c);
     (void)hipFree(st->d_z);
+    (void)hipFree(st->d_s); (void)hipFree(st->d_s2); (void)hipFree(st->d_FL); (void)hipFree(st->d_FR);
+    if (st->ev) (void)hipEventDestroy(st->ev);
     delete st;
 }
 size_t halo_ipa_len(const halo_ipa *st) { return st ? st->m : 0; }
@@ -447,6 +509,11 @@ int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
     host::Point acc = host::Point::infinity();
     for (size_t i = 0; i < k; ++i) acc = acc + host::Point::load(pts_jac + 12 * i);  // fixed rank order 0..k-1
     acc.store_normalized(out);
+    return HALO_OK;
+}
+int halo_set_ipa_switch(halo_ctx *ctx, size_t size) {
+    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
+    ctx->nofold_size = size;
     return HALO_OK;
 }
 int halo_set_window_bits(halo_ctx *ctx, int c) {

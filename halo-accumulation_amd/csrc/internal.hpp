@@ -86,6 +86,7 @@ struct halo_ctx {
     halo::MsmWorkspace wss[2];         // two slots so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
+    size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
@@ -100,6 +101,11 @@ struct halo_ipa {
     uint32_t *d_G = nullptr;  // m x 20 words native affine (in-place)
     uint64_t *d_c = nullptr;  // m x 4
     uint64_t *d_z = nullptr;  // m x 4
+    hipEvent_t ev = nullptr;  // orders slot 1's stream after the folds queued on stream 0
+    // no-fold mode (ipa.hip): G stays at M points, s holds the challenge products
+    bool nofold = false;
+    size_t M = 0, s_len = 0;
+    uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
 };
 
 namespace halo {
@@ -135,6 +141,8 @@ int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, co
 int rng_scalars_dev(halo_ctx *ctx, uint64_t state0, size_t n, uint64_t *d_out);
 int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, uint64_t *d_out);
 int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a);
+int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_L, uint64_t *d_R);
+int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out);
 
 // ---- abi.hip (device-pointer forms used by pcdl_acc.hip)
 int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out);

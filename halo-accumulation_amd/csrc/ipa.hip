@@ -276,6 +276,39 @@ __global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const ui
     fe_store(y + 4 * (size_t)i, fe_add<FrCfg>(fe_load(y + 4 * (size_t)i), fe_mul<FrCfg>(a, fe_load(x + 4 * (size_t)i))));
 }
 
+
+// ------------------------------------------------------------------ "no-fold" late rounds
+// Once the key has been folded down to M points (G0), folding it further is latency-bound
+// (one uniform scalar multiplication is a ~1 ms serial chain whatever m is).  Instead G0 stays
+// fixed and the folded key is kept implicitly:  G_k[j] = sum_t s[t] * G0[j + t*m]  with
+// s = products of the challenges since the switch.  Then
+//   L = <c_r, G_l> = sum_{b: (b mod m) <  m/2} (c[(b mod m) + m/2] * s[b div m]) * G0[b]
+//   R = <c_l, G_r> = sum_{b: (b mod m) >= m/2} (c[(b mod m) - m/2] * s[b div m]) * G0[b]
+// are two MSMs over the fixed G0 (half of each scalar vector is zero and is skipped at recode).
+__global__ __launch_bounds__(256) void k_nofold_expand(const uint64_t *__restrict__ c, const uint64_t *__restrict__ sv, uint32_t m,
+                                                       int log2m, uint32_t M, uint64_t *__restrict__ outL, uint64_t *__restrict__ outR) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= M) return;
+    uint32_t u = b & (m - 1), t = b >> log2m, h = m >> 1;
+    Fe sc = fe_load(sv + 4 * (size_t)t);
+    if (u < h) {
+        fe_store(outL + 4 * (size_t)b, fe_mul<FrCfg>(fe_load(c + 4 * (size_t)(u + h)), sc));
+        fe_store(outR + 4 * (size_t)b, fe_zero());
+    } else {
+        fe_store(outR + 4 * (size_t)b, fe_mul<FrCfg>(fe_load(c + 4 * (size_t)(u - h)), sc));
+        fe_store(outL + 4 * (size_t)b, fe_zero());
+    }
+}
+// s'[2t + u] = s[t] * xi^u : the stride of the implicit key halves (pcdl.rs:218 applied to the representation)
+__global__ __launch_bounds__(256) void k_nofold_s_update(const uint64_t *__restrict__ s_in, uint32_t len, FeArg xi,
+                                                         uint64_t *__restrict__ s_out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * len) return;
+    Fe v = fe_load(s_in + 4 * (size_t)(i >> 1));
+    if (i & 1) v = fe_mul<FrCfg>(v, from_arg(xi));
+    fe_store(s_out + 4 * (size_t)i, v);
+}
+
 // ================================================================== host launchers
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
@@ -411,6 +444,21 @@ int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, 
 int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a) {
     if (n == 0) return HALO_OK;
     HALO_LAUNCH(ctx, "k_axpy", k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_y, d_x, (uint32_t)n, to_arg(a));
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_L, uint64_t *d_R) {
+    int log2m = 0;
+    while (((size_t)1 << log2m) < m) log2m++;
+    HALO_LAUNCH(ctx, "k_nofold_expand", k_nofold_expand, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_c, d_s, (uint32_t)m, log2m,
+                (uint32_t)M, d_L, d_R);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out) {
+    HALO_LAUNCH(ctx, "k_nofold_s_update", k_nofold_s_update, dim3((unsigned)((2 * len + 255) / 256)), dim3(256), 0, d_s_in, (uint32_t)len,
+                to_arg(xi), d_s_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

@@ -22,7 +22,9 @@ namespace halo {
 MsmPlan msm_plan(size_t n, int forced_c) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = forced_c > 0 ? forced_c : lg - 4;
+    // large MSMs are throughput-bound: ~32 points per bucket amortise the bucket reduction;
+    // below 2^18 points the serial chain per bucket dominates, so spread over more buckets
+    int c = forced_c > 0 ? forced_c : (lg >= 18 ? lg - 4 : lg - 2);
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     MsmPlan p;
@@ -176,12 +178,13 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *blocksum, uint32_t 
 // with two real bits, put n/4 .. n points into one bucket).  ntask[g] = ceil(count/KMAX);
 // toff = exclusive scan of ntask.  One lane per task; a bucket's value is the partial of its
 // first task once k_msm_combine_big has folded the partials of multi-task buckets into it.
-constexpr uint32_t KMAX = 64;
+constexpr uint32_t KMAX = 64;  // largest task length (plan.kmax <= KMAX)
 
-__global__ __launch_bounds__(256) void k_msm_ntasks(const uint32_t *__restrict__ counts, uint32_t total, uint32_t *__restrict__ ntask) {
+__global__ __launch_bounds__(256) void k_msm_ntasks(const uint32_t *__restrict__ counts, uint32_t total, uint32_t kmax,
+                                                    uint32_t *__restrict__ ntask) {
     uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
-    ntask[g] = (counts[g] + KMAX - 1) / KMAX;
+    ntask[g] = (counts[g] + kmax - 1) / kmax;
 }
 
 HALO_DEV uint32_t scan_at(const uint32_t *__restrict__ in_block, const uint32_t *__restrict__ blockoff, uint32_t g) {
@@ -207,19 +210,20 @@ __global__ __launch_bounds__(256) void k_msm_task_meta(const uint32_t *__restric
 // aggregated per block in LDS so that only <= 65 global atomics per block are issued.
 // meta[2 .. 2+65) = bin totals, meta[70 .. 70+65) = bin cursors.
 HALO_DEV void task_locate(const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
-                          const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t t, uint32_t &g, uint32_t &len) {
+                          const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t kmax, uint32_t t, uint32_t &g,
+                          uint32_t &len) {
     uint32_t lo = 0, hi = total_buckets - 1;
     while (lo < hi) {
         uint32_t mid = (lo + hi + 1) >> 1;
         if (scan_at(toff, tblockoff, mid) <= t) lo = mid; else hi = mid - 1;
     }
     g = lo;
-    uint32_t first = (t - scan_at(toff, tblockoff, g)) * KMAX;
+    uint32_t first = (t - scan_at(toff, tblockoff, g)) * kmax;
     len = counts[g] - first;
-    if (len > KMAX) len = KMAX;
+    if (len > kmax) len = kmax;
 }
 __global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
-                                                       const uint32_t *__restrict__ counts, uint32_t total_buckets,
+                                                       const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t kmax,
                                                        uint32_t *__restrict__ meta, uint32_t *__restrict__ task_g) {
     __shared__ uint32_t bins[KMAX + 1];
     if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restric
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t < meta[0]) {
         uint32_t g, len;
-        task_locate(toff, tblockoff, counts, total_buckets, t, g, len);
+        task_locate(toff, tblockoff, counts, total_buckets, kmax, t, g, len);
         task_g[t] = g | ((KMAX - len) << 24);  // bucket id (< 2^20) and bin = 64 - len
         atomicAdd(&bins[KMAX - len], 1u);
     }
@@ -261,14 +265,14 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
                                                         const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
                                                         const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
                                                         const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_g,
-                                                        uint32_t *__restrict__ partial) {
+                                                        uint32_t kmax, uint32_t *__restrict__ partial) {
     uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     if (tid >= meta[0]) return;
     uint32_t t = order[tid];
     uint32_t g = task_g[t] & 0xFFFFFFu;
-    uint32_t first = (t - scan_at(toff, tblockoff, g)) * KMAX;
+    uint32_t first = (t - scan_at(toff, tblockoff, g)) * kmax;
     uint32_t cnt = counts[g] - first;
-    if (cnt > KMAX) cnt = KMAX;
+    if (cnt > kmax) cnt = kmax;
     uint32_t st = scan_at(starts, blockoff, g) + first;
     XyzzN acc = xyzz_inf();
     for (uint32_t k = 0; k < cnt; k++) {
@@ -613,7 +617,11 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
     // tasks <= non-empty buckets + entries / KMAX
-    ws.cap_tasks = ws.cap_counts + ws.cap_sorted / KMAX + 1;
+    {   // tasks: one per non-empty bucket plus entries / kmax (kmax = 16 only below 2^18 points, W <= 32 there)
+        size_t small = ws.cap_sorted < ((size_t)1 << 23) ? ws.cap_sorted : ((size_t)1 << 23);
+        size_t extra = ws.cap_sorted / KMAX > small / 16 ? ws.cap_sorted / KMAX : small / 16;
+        ws.cap_tasks = ws.cap_counts + extra + 1;
+    }
     HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_ntask, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
@@ -690,27 +698,32 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
                 ws.d_starts, ws.d_blockoff, ws.d_sorted);
     dim3 gridb((unsigned)((total + 255) / 256));
     HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
-    HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, ws.d_ntask);
+    // chain bound per lane: 64 where the launch is throughput-bound, 16 where it is latency-bound
+    uint32_t kmax = n >= ((size_t)1 << 18) ? KMAX : 16u;
+    HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, kmax, ws.d_ntask);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
     HALO_LAUNCH(ctx, "k_msm_task_meta", k_msm_task_meta, gridb, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, (uint32_t)total, ws.d_meta,
                 ws.d_biglist);
-    size_t max_tasks = total + n * (size_t)p.W / KMAX + 1;
+    size_t max_tasks = total + n * (size_t)p.W / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
-    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, ws.d_meta,
+    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax, ws.d_meta,
                 ws.d_task_g);
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
     HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
-                ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, ws.d_buckets);
+                ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine_small", k_msm_combine_small, dim3(512), b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
                 ws.d_biglist, (uint32_t)total, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine_big", k_msm_combine_big, dim3(1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
                 ws.d_biglist, ws.d_buckets);
     uint32_t L, nseg;
     int logL = 0;
-    if (p.B <= 512) { nseg = 1; L = p.B >= 64 ? p.B / 64 : 1; }
-    else { L = 8; nseg = p.B / 512; }
+    // one bucket per lane while that keeps <= 64 segments per window (shortest serial chain),
+    // more buckets per lane only for the large windows
+    if (p.B <= 64) { nseg = 1; L = 1; }
+    else if (p.B <= 4096) { L = 1; nseg = p.B / 64; }
+    else { L = p.B / 4096; nseg = 64; }
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);

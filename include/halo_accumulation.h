@@ -145,6 +145,9 @@ int halo_prof_count(halo_ctx *ctx);
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
 /* sum of k Jacobian points in index order, on the host (combine step of the sharded MSM) */
 int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]);
+/* IPA tuning: key size at which halo_ipa_* stops folding G and switches to MSMs over the fixed
+ * folded key (default 2^16; 0 or 1 = always fold).  Results are identical either way. */
+int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 /* MSM tuning: window bits (0 = automatic) */
 int halo_set_window_bits(halo_ctx *ctx, int c);
 

@@ -78,7 +78,7 @@ def test_h_eval_batch_and_accumulate(ctx):
     assert [orc.fr_from_mont(g) for g in got] == want
 
 
-def test_u_check(hal, ctx):
+def test_u_check(hal, ctx, ipa_mode):
     """pcdl.rs:382-438 with xi = [0,1,2,3]: device fold of G == MSM(GS, h_coeffs) == SURVEY anchor."""
     xm = orc.scalars_to_mont([0, 1, 2, 3])
     zero = np.zeros((8, 4), dtype=np.uint64)
@@ -94,8 +94,17 @@ def test_u_check(hal, ctx):
     assert [orc.fr_from_mont(c) for c in ctx.h_coeffs(xm)] == [1, 3, 2, 6, 1, 3, 2, 6]
 
 
+@pytest.fixture(params=[0, 1 << 16, 16], ids=["always-fold", "default-switch", "switch-at-16"])
+def ipa_mode(request, ctx):
+    """Both IPA strategies must give the reference's results: folding G every round (k_fold_points)
+    and the no-fold late rounds (MSMs over the fixed folded key)."""
+    ctx.set_ipa_switch(request.param)
+    yield request.param
+    ctx.set_ipa_switch(1 << 16)
+
+
 @pytest.mark.parametrize("n", [2, 8, 64, 1024])
-def test_ipa_rounds_vs_oracle(hal, ctx, pp, n):
+def test_ipa_rounds_vs_oracle(hal, ctx, pp, n, ipa_mode):
     """Kernel-level parity of pcdl.rs:195-227: L, R and the folded state, round by round."""
     gs = ctx.read_bases(0, n)
     coeffs, s = orc.rng_scalars(n, n - 1 if n > 2 else n)
@@ -143,7 +152,7 @@ def test_pedersen_homomorphism(hal, ctx):
 
 
 @pytest.mark.parametrize("n,hiding", [(4, False), (4, True), (16, True), (512, False), (512, True), (4096, True)])
-def test_open_check_matches_oracle(hal, ctx, pp, n, hiding):
+def test_open_check_matches_oracle(hal, ctx, pp, n, hiding, ipa_mode):
     """pcdl.rs:441-483 completeness, and proof blobs identical to the CPU restatement's."""
     from halo_accumulation_amd import pcdl
     d = n - 1
@@ -215,3 +224,24 @@ def test_acc_scheme_matches_oracle(hal, ctx, pp, n, steps):
             A.verifier(ctx, d, qs, bad)
     A.decider(ctx, acc)
     orc.acc_decider(pp, acc)
+
+
+def test_open_2_17_both_strategies_agree(hal):
+    """n = 2^17: one real fold round then no-fold rounds, against folding all the way; the
+    verifier (succinct check + U == commit(h)) accepts and the proofs are identical."""
+    from halo_accumulation_amd import pcdl
+    n = 1 << 17
+    d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        coeffs, s = orc.rng_scalars(0x48414C4F00000003, n)
+        zw, _ = orc.rng_scalars(s, 2)
+        C = pcdl.commit(c, coeffs, d, zw[1])
+        proofs = []
+        for switch in (1 << 16, 0, 1 << 10):
+            c.set_ipa_switch(switch)
+            proofs.append(pcdl.open(c, [5], coeffs, C, d, zw[0], zw[1]))
+        assert proofs[0].tolist() == proofs[1].tolist() == proofs[2].tolist()
+        pcdl.check_proof(c, C, d, zw[0], c.poly_eval(coeffs, zw[0]), proofs[0])
+    finally:
+        c.close()
