@@ -101,6 +101,10 @@ def main():
         acc_ms, acc_cnt = prof.get("k_msm_accumulate", (0.0, 0))
         kern_s = acc_ms / max(acc_cnt, 1) * 1e-3
         alg_bytes = 96 * (hi - lo) + 64  # 64 B base + 32 B scalar per point, one point out
+        traffic = None  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (n = 2^20, 1 GPU only)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.log_n == 20 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["kernels"].get("k_msm_accumulate", {}).get("traffic_bytes_per_launch")
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         result = {
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
@@ -111,7 +115,7 @@ def main():
                        "sharding": "block index shard per rank + RCCL all-gather of 96 B partials" if world > 1 else "single GPU",
                        "window_bits": "auto (c = floor(log2 n) - 4, clamped to [4,16])"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes": alg_bytes,
                          "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
             "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
