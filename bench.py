@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--depth", type=int, default=4, help="independent MSMs in flight (1..4)")
     ap.add_argument("--open-steps", type=int, default=2, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     args = ap.parse_args()
@@ -64,16 +65,24 @@ def main():
     # N > 1, all-gathered and combined) inside the timed region.
     gather = ShardedMsm(lambda slot: ctx.msm_dev_end(slot), h._lib.point_sum, device=dev)
 
+    depth = args.depth
+
     def run_steps(k):
-        out, pending = None, None
+        # local partials are combined across ranks in batches of `depth` (one all-gather per batch)
+        out, pending, parts = None, [], []
         for step in range(k):
-            slot = step & 1
+            slot = step % depth
+            if len(pending) == depth:
+                parts.append(ctx.msm_dev_end(pending.pop(0)))
+                if len(parts) == depth:
+                    out = gather.gather_batch(parts)[-1]
+                    parts = []
             ctx.msm_dev_begin(slot, d_sc.data_ptr(), hi - lo)
-            if pending is not None:
-                out = gather(pending)
-            pending = slot
-        if pending is not None:
-            out = gather(pending)
+            pending.append(slot)
+        while pending:
+            parts.append(ctx.msm_dev_end(pending.pop(0)))
+        if parts:
+            out = gather.gather_batch(parts)[-1]
         return out
 
     def barrier():
@@ -113,6 +122,7 @@ def main():
             "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
                        "sharding": "block index shard per rank + RCCL all-gather of 96 B partials" if world > 1 else "single GPU",
+                       "msms_in_flight": depth,
                        "window_bits": "auto (c = floor(log2 n) - 4, clamped to [4,16])"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

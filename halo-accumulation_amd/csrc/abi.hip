@@ -63,14 +63,13 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipSetDevice(device));
     ctx->device = device;
     ctx->n = n;
-    HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking));
-    HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[1], hipStreamNonBlocking));
+    for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
     ctx->stream = ctx->streams[0];
-    HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 80));
+    HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 128));
     size_t tn = n < 64 ? 64 : n;
     ctx->tmp_words = tn * 12;
     HALO_HIP(hipMalloc(&ctx->d_tmp_a, tn * 12 * 8));
-    HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 10 * 8));
+    HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 16 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
     return msm_workspace_alloc(ctx, n, 0);
@@ -122,9 +121,9 @@ int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, cons
     int rc = HALO_OK;
     if (hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) { delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
     do {
-        if (hipMalloc(&st->d_G, n * 80) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
+        if (hipMalloc(&st->d_G, n * 128) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
             hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
-        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 80, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
         }
@@ -208,7 +207,7 @@ void *halo_ctx_stream(halo_ctx *ctx) { return ctx ? (void *)ctx->stream : nullpt
 int halo_ctx_read_bases(halo_ctx *ctx, size_t off, size_t n, uint64_t *out) {
     HALO_CTX(ctx);
     if (off + n > ctx->n || !out) { set_error("read_bases: range"); return HALO_E_ARG; }
-    int rc = aff_native_to_words(ctx, ctx->d_bases + 20 * off, n, ctx->d_tmp_a);
+    int rc = aff_native_to_words(ctx, ctx->d_bases + 32 * off, n, ctx->d_tmp_a);
     if (rc) return rc;
     return download(ctx, out, ctx->d_tmp_a, n * 8);
 }
@@ -225,7 +224,7 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
     HALO_CTX(ctx);
     if (off + n > ctx->n || !out || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     host::Point r;
-    int rc = msm_run(ctx, ctx->d_bases + 20 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n, &r);
+    int rc = msm_run(ctx, ctx->d_bases + 32 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -234,7 +233,7 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
 int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int mont) {
     HALO_CTX(ctx);
     if (off + n > ctx->n || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
-    return msm_enqueue(ctx, slot, ctx->d_bases + 20 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n);
+    return msm_enqueue(ctx, slot, ctx->d_bases + 32 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n);
 }
 int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
     HALO_CTX(ctx);
@@ -403,7 +402,7 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     } else {
         rc = msm_enqueue(ctx, 0, st->d_G, st->d_c + 4 * m, true, m);
         if (rc) return rc;
-        rc = msm_enqueue(ctx, 1, st->d_G + 20 * m, st->d_c, true, m);
+        rc = msm_enqueue(ctx, 1, st->d_G + 32 * m, st->d_c, true, m);
     }
     if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
     rc = msm_finish(ctx, 0, &Lp);
@@ -481,8 +480,7 @@ size_t halo_ipa_len(const halo_ipa *st) { return st ? st->m : 0; }
 // ------------------------------------------------------------------ measurement hooks
 int halo_prof_enable(halo_ctx *ctx, int on) {
     HALO_CTX(ctx);
-    HALO_HIP(hipStreamSynchronize(ctx->streams[0]));
-    HALO_HIP(hipStreamSynchronize(ctx->streams[1]));
+    for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
     ctx->prof.collect();
     ctx->prof.on = on != 0;
     ctx->prof.dominant_only = on == 2;
@@ -490,8 +488,7 @@ int halo_prof_enable(halo_ctx *ctx, int on) {
 }
 int halo_prof_reset(halo_ctx *ctx) {
     HALO_CTX(ctx);
-    HALO_HIP(hipStreamSynchronize(ctx->streams[0]));
-    HALO_HIP(hipStreamSynchronize(ctx->streams[1]));
+    for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
     ctx->prof.collect();
     for (auto &e : ctx->prof.entries) { e.total_ms = 0; e.launches = 0; }
     return HALO_OK;

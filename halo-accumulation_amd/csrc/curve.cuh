@@ -26,7 +26,8 @@ struct AffN { Fq<2> x, y; };
 struct XyzzN { Fq<8> x, y; Fq<2> zz, zzz; };
 struct JacN { Fq<8> x, y; Fq<4> z; };
 
-constexpr int AFF_WORDS = 20;   // native affine point in memory
+constexpr int AFF_WORDS = 20;   // words of a native affine point (9 limbs + pad, twice)
+constexpr int AFF_STRIDE = 32;  // table stride in words: 128 B, so a gather touches exactly one 128-byte line
 constexpr int XYZZ_WORDS = 40;  // native XYZZ point in memory
 
 // ---------------------------------------------------------------- affine

@@ -77,13 +77,15 @@ struct MsmWorkspace {
 
 }  // namespace halo
 
+constexpr int HALO_SLOTS = 4;
+
 struct halo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
-    hipStream_t streams[2] = {nullptr, nullptr};
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t n = 0;
     uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.cuh AffN)
-    halo::MsmWorkspace wss[2];         // two slots so that independent MSMs can overlap
+    halo::MsmWorkspace wss[4];         // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)

@@ -47,8 +47,8 @@ HALO_DEV Fq<2> pick3(int e, const Fq<2> &a, const Fq<2> &b, const Fq<2> &c) {
 __global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, uint32_t m, GlvArg a) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
-    AffN hi = aff_load(G + AFF_WORDS * (size_t)(j + m));
-    AffN lo = aff_load(G + AFF_WORDS * (size_t)j);
+    AffN hi = aff_load(G + AFF_STRIDE * (size_t)(j + m));
+    AffN lo = aff_load(G + AFF_STRIDE * (size_t)j);
     if (aff_is_inf(hi)) return;  // G[j] + xi * infinity = G[j]
     constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
     constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, u
         }
     }
     acc = jac_madd(acc, lo);
-    aff_store(G + AFF_WORDS * (size_t)j, jac_to_aff(acc));
+    aff_store(G + AFF_STRIDE * (size_t)j, jac_to_aff(acc));
 }
 
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     XyzzN acc = xyzz_inf();
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t e = sorted[st + k];
-        AffN p = aff_load(bases + AFF_WORDS * (size_t)(e & 0x7fffffffu));
+        AffN p = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
         p = aff_cneg(p, (e >> 31) != 0);
         xyzz_madd(acc, p);
     }
@@ -396,18 +396,18 @@ __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__
 __global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    aff_store(out + AFF_WORDS * (size_t)i, jac_to_aff(jac_from_words(jac + 12 * (size_t)i)));
+    aff_store(out + AFF_STRIDE * (size_t)i, jac_to_aff(jac_from_words(jac + 12 * (size_t)i)));
 }
 // arkworks affine words (n x 8 u64) -> native table (n x 20 words)
 __global__ __launch_bounds__(256) void k_aff_to_native(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    aff_store(out + AFF_WORDS * (size_t)i, aff_from_words(in + 8 * (size_t)i));
+    aff_store(out + AFF_STRIDE * (size_t)i, aff_from_words(in + 8 * (size_t)i));
 }
 __global__ __launch_bounds__(256) void k_native_to_aff(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    aff_to_words(out + 8 * (size_t)i, aff_load(in + AFF_WORDS * (size_t)i));
+    aff_to_words(out + 8 * (size_t)i, aff_load(in + AFF_STRIDE * (size_t)i));
 }
 // table[w][d] = d * 16^w * (-1, 2), d in 0..15 (d = 0 stored as infinity): 64 mixed adds, no doublings
 __global__ __launch_bounds__(256) void k_urs(const uint32_t *__restrict__ table, const uint32_t *__restrict__ canon, uint32_t n,
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(256) void k_urs(const uint32_t *__restrict__ table,
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             uint32_t nib = (word >> (4 * k)) & 15u;
-            AffN t = aff_load(table + AFF_WORDS * (size_t)((limb * 8 + k) * 16 + nib));
+            AffN t = aff_load(table + AFF_STRIDE * (size_t)((limb * 8 + k) * 16 + nib));
             acc = jac_madd(acc, t);
         }
     }
-    aff_store(out + AFF_WORDS * (size_t)i, jac_to_aff(acc));
+    aff_store(out + AFF_STRIDE * (size_t)i, jac_to_aff(acc));
 }
 
 // ------------------------------------------------------------------------------ test hooks
@@ -580,7 +580,7 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out)
     uint64_t *d_tbl = nullptr, *d_canon = nullptr;
     uint32_t *d_tbl_native = nullptr;
     HALO_HIP(hipMalloc(&d_tbl, tbl.size() * 8));
-    HALO_HIP(hipMalloc(&d_tbl_native, (size_t)1024 * AFF_WORDS * 4));
+    HALO_HIP(hipMalloc(&d_tbl_native, (size_t)1024 * AFF_STRIDE * 4));
     HALO_HIP(hipMalloc(&d_canon, canon.size() * 8));
     HALO_HIP(hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HALO_HIP(hipMemcpyAsync(d_canon, canon.data(), canon.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -636,7 +636,7 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     return HALO_OK;
 }
 void msm_workspace_free(halo_ctx *ctx) {
-    for (int slot = 0; slot < 2; ++slot) {
+    for (int slot = 0; slot < HALO_SLOTS; ++slot) {
         MsmWorkspace &ws = ctx->wss[slot];
         uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
         uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff,
@@ -663,7 +663,7 @@ struct StreamGuard {  // the launch macro uses ctx->stream
 };
 
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
-    if (slot < 0 || slot > 1) { set_error("msm: slot must be 0 or 1"); return HALO_E_ARG; }
+    if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
     if (!ctx->wss[slot].d_counts) {
         int rc = msm_workspace_alloc(ctx, ctx->wss[0].cap_n, slot);
         if (rc) return rc;
@@ -737,13 +737,15 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
 
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out) {
     *out = host::Point::infinity();
-    if (slot < 0 || slot > 1 || !ctx->wss[slot].in_flight) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
+    if (slot < 0 || slot >= HALO_SLOTS || !ctx->wss[slot].in_flight) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
     MsmWorkspace &ws = ctx->wss[slot];
     ws.in_flight = false;
     MsmPlan p = ws.plan;
     if (p.W == 0) return HALO_OK;  // n == 0
     HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
-    if (ctx->prof.on && !ctx->wss[slot ^ 1].in_flight) ctx->prof.collect();
+    bool others = false;
+    for (int k = 0; k < HALO_SLOTS; ++k) others = others || ctx->wss[k].in_flight;
+    if (ctx->prof.on && !others) ctx->prof.collect();
     host::Point acc = host::Point::infinity();
     for (int w = p.W - 1; w >= 0; --w) {
         if (!acc.is_inf())

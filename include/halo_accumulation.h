@@ -66,8 +66,8 @@ int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
 /* same, scalars already in device memory (n x 4 limbs, 32-byte aligned device pointer) */
 int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int scalars_are_mont, uint64_t out_jac[12]);
-/* Asynchronous halves of halo_msm_dev, for overlapping independent MSMs: `slot` (0 or 1) selects
- * one of the context's two workspaces/streams; begin() only enqueues, end() waits and combines.
+/* Asynchronous halves of halo_msm_dev, for overlapping independent MSMs: `slot` (0..3) selects
+ * one of the context's four workspaces/streams (allocated on first use); begin() only enqueues, end() waits and combines.
  * At most one MSM per slot in flight; the scalars must stay untouched until end(). */
 int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int scalars_are_mont);
 int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out_jac[12]);

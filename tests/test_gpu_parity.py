@@ -261,3 +261,36 @@ def test_msm_2_20_linearity(ctx1m):
     hi = ctx1m.msm(a[n // 2:], off=n // 2)
     want = orc.z(12); orc.lib().orc_point_add(orc.ptr(lo), orc.ptr(hi), orc.ptr(want))
     assert full.tolist() == want.tolist()
+
+
+def test_msm_2_20_adversarial_scalars_stay_fast_and_exact(ctx1m):
+    """All-equal scalars put every point of a window into ONE bucket (n entries): the task split
+    must keep that bounded.  all-one against the oracle; k * all-one by linearity; wall-clock bound."""
+    import time
+    n = 1 << 20
+    gs = ctx1m.read_bases()
+    one = np.ascontiguousarray(np.tile(orc.fr_to_mont(1), (n, 1)))
+    t = time.time(); got = ctx1m.msm(one); dt_one = time.time() - t
+    assert got.tolist() == orc.msm_affine(gs, one).tolist()
+    k, _ = orc.rng_scalars(99, 1)
+    same = np.ascontiguousarray(np.tile(k[0], (n, 1)))
+    t = time.time(); got_k = ctx1m.msm(same); dt_same = time.time() - t
+    want = orc.z(12); orc.lib().orc_point_mul(orc.ptr(got), orc.ptr(k[0]), orc.ptr(want))
+    assert got_k.tolist() == want.tolist()
+    assert dt_one < 0.5 and dt_same < 0.5, (dt_one, dt_same)
+
+
+def test_msm_pipelined_slots_agree(ctx1m):
+    """halo_msm_dev_begin/_end on all four slots, interleaved, equals the synchronous call."""
+    import torch
+    n = 1 << 18
+    scs = [orc.rng_scalars(1000 + i, n)[0] for i in range(4)]
+    want = [ctx1m.msm(s).tolist() for s in scs]
+    ds = [torch.from_numpy(s.view(np.int64)).cuda() for s in scs]
+    for rep in range(2):
+        for slot in range(4):
+            ctx1m.msm_dev_begin(slot, ds[slot].data_ptr(), n)
+        for slot in (2, 0, 3, 1):
+            assert ctx1m.msm_dev_end(slot).tolist() == want[slot]
+    with pytest.raises(Exception):
+        ctx1m.msm_dev_end(0)  # nothing in flight

@@ -245,3 +245,26 @@ def test_open_2_17_both_strategies_agree(hal):
         pcdl.check_proof(c, C, d, zw[0], c.poly_eval(coeffs, zw[0]), proofs[0])
     finally:
         c.close()
+
+
+def test_acc_chain_2_20_completeness(hal):
+    """BASELINE config 4 shape at full size, two steps of benches/acc.rs:76-98: random_instance +
+    prover, each accepted by the verifier, then the decider (pcdl::check with the n = 2^20 MSM)."""
+    from halo_accumulation_amd import acc as A
+    n = 1 << 20
+    d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        rng = [0x48414C4F00000004]
+        acc = None
+        for _ in range(2):
+            q = A.random_instance(c, rng, d)
+            qs = [q] if acc is None else [A.instance_from_accumulator(c, acc, d), q]
+            acc = A.prover(c, rng, d, qs)
+            A.verifier(c, d, qs, acc)
+        A.decider(c, acc)
+        bad = acc.copy(); bad[13] ^= 1  # z
+        with pytest.raises(ValueError):
+            A.decider(c, bad)
+    finally:
+        c.close()

@@ -34,6 +34,12 @@ def _worker(rank, world, port, n, q):
     sc, _ = orc.rng_scalars(0x48414C4F00000005, n)    # every rank derives the same scalar stream
     msm = ShardedMsm(lambda: orc.msm_affine(gs, np.ascontiguousarray(sc[lo:hi])), h._lib.point_sum)
     out = msm()
+    # batched form: three partials (the local one, twice, and the point at infinity) in one collective
+    inf = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], dtype=np.uint64)
+    part = orc.msm_affine(gs, np.ascontiguousarray(sc[lo:hi]))
+    batch = msm.gather_batch([part, inf, part])
+    assert batch[0].tolist() == out.tolist() == batch[2].tolist()
+    assert orc.point_canonical(batch[1]) is None
     q.put((rank, out.tolist(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()

@@ -26,10 +26,10 @@ for c in ([0] if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(",")]
     t = time.time()
     for _ in range(K): out = ctx.msm_dev(d.data_ptr(), n)
     print("   unprofiled: %.3f ms per MSM" % ((time.time() - t) / K * 1e3), flush=True)
-    K2 = 40; t = time.time(); pend = None
-    for i in range(K2):
-        ctx.msm_dev_begin(i & 1, d.data_ptr(), n)
-        if pend is not None: out2 = ctx.msm_dev_end(pend)
-        pend = i & 1
-    out2 = ctx.msm_dev_end(pend)
-    print("   pipelined (2 slots): %.3f ms per MSM   same result: %s" % ((time.time() - t) / K2 * 1e3, out2.tolist() == out.tolist()), flush=True)
+    for depth in (2, 4):
+        K2 = 40; t = time.time(); pend = []
+        for i in range(K2):
+            if len(pend) == depth: out2 = ctx.msm_dev_end(pend.pop(0))
+            ctx.msm_dev_begin(i % depth, d.data_ptr(), n); pend.append(i % depth)
+        while pend: out2 = ctx.msm_dev_end(pend.pop(0))
+        print("   pipelined depth %d: %.3f ms per MSM   same result: %s" % (depth, (time.time() - t) / K2 * 1e3, out2.tolist() == out.tolist()), flush=True)
