@@ -7,6 +7,7 @@
 // What stays on the host, exactly as in the reference: Fiat-Shamir hashing (rho_0!/rho_1!),
 // challenge inversion, the O(lg n) succinct check and the struct packing.
 #include <memory>
+#include <thread>
 
 #include "internal.hpp"
 
@@ -275,15 +276,28 @@ static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t
     int rc = pcdl_commit_host(ctx, h0w, 2, d, nullptr, &chk);  // :152-155
     if (rc) return rc;
     if (U0 != chk) return fail_reject("U_0 != PCDL.Commit(h_0)");
-    for (size_t i = 0; i < m; ++i) {
+    // :158-170  the m succinct checks are independent host work (hashing + a 2 lg n + 1 point MSM
+    // each): one thread per instance; errors are reported in instance order like the serial loop
+    struct CheckResult { int rc = HALO_OK; std::string err; std::vector<Fr> xis; Point U; };
+    std::vector<CheckResult> res(m);
+    auto run_one = [&](size_t i) {
         const uint64_t *q = qs + i * iw;
-        std::vector<Fr> xis;
-        Point U;
-        rc = succinct_check_host(ctx, Point::load(q), (size_t)q[12], Fr::load(q + 13), Fr::load(q + 17), q + 21, &xis, &U);  // :164
-        if (rc) return rc;
-        hs->xis.push_back(std::move(xis));
-        Us.push_back(U);
-        if ((size_t)q[12] != d) return fail_reject("d_i != d");  // :169
+        res[i].rc = succinct_check_host(ctx, Point::load(q), (size_t)q[12], Fr::load(q + 13), Fr::load(q + 17), q + 21, &res[i].xis,
+                                        &res[i].U);  // :164
+        if (res[i].rc) res[i].err = halo_last_error();
+    };
+    if (m <= 1) {
+        for (size_t i = 0; i < m; ++i) run_one(i);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < m; ++i) th.emplace_back(run_one, i);
+        for (auto &t : th) t.join();
+    }
+    for (size_t i = 0; i < m; ++i) {
+        if (res[i].rc) { set_error(res[i].err); return res[i].rc; }
+        hs->xis.push_back(std::move(res[i].xis));
+        Us.push_back(res[i].U);
+        if ((size_t)(qs + i * iw)[12] != d) return fail_reject("d_i != d");  // :169
     }
     // :173  alpha = rho_1(hs): h_0 Some(poly), hs Vec<HPoly>, alpha None, alphas empty
     Transcript t;

@@ -1,0 +1,38 @@
+"""BASELINE config 4: ASDL prover + verifier + decider over K accumulated instances at n = 2^lg
+(the shape of the reference's benches/acc.rs:64-98: K x (random_instance + prover), then
+K x verifier + 1 x decider).  Prints one JSON line; results are checked by the scheme itself
+(every verifier and the decider must accept)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import halo_accumulation_amd as h
+from halo_accumulation_amd import acc as A
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n = 1 << lg; d = n - 1
+ctx = h._lib.Context(urs_n=n)
+rng = [0x48414C4F00000004]
+accs, qss, acc = [], [], None
+t0 = time.perf_counter(); t_inst = 0.0; t_prov = 0.0
+for _ in range(K):
+    t = time.perf_counter(); q = A.random_instance(ctx, rng, d); t_inst += time.perf_counter() - t
+    qs = [q] if acc is None else [A.instance_from_accumulator(ctx, acc, d), q]
+    t = time.perf_counter(); acc = A.prover(ctx, rng, d, qs); t_prov += time.perf_counter() - t
+    accs.append(acc); qss.append(qs)
+t_chain = time.perf_counter() - t0
+t = time.perf_counter()
+for a, qs in zip(accs, qss):
+    A.verifier(ctx, d, qs, a)
+t_ver = time.perf_counter() - t
+t = time.perf_counter(); A.decider(ctx, accs[-1]); t_dec = time.perf_counter() - t
+t = time.perf_counter()
+for a in accs[: min(K, 8)]:
+    A.decider(ctx, a)
+t_slow = (time.perf_counter() - t) / min(K, 8)
+print(json.dumps({"config": "ASDL over %d accumulated instances, n=2^%d, 1 GPU" % (K, lg),
+                  "prover_chain_s": t_chain, "random_instance_ms_each": t_inst / K * 1e3, "prover_ms_each": t_prov / K * 1e3,
+                  "fast_check_s (K verifiers + 1 decider, benches/acc.rs:64-74)": t_ver + t_dec,
+                  "verifier_ms_each": t_ver / K * 1e3, "decider_ms": t_dec * 1e3,
+                  "slow_check_s (K deciders, benches/acc.rs:100-106, extrapolated from %d)" % min(K, 8): t_slow * K,
+                  "all_accepted": True}))

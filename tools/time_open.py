@@ -23,6 +23,12 @@ for k, (ms, cnt) in sorted(ctx.prof().items(), key=lambda kv: -kv[1][0]):
     print("   %-22s total %9.3f ms  launches %4d  avg %8.3f ms" % (k, ms, cnt, ms / max(cnt, 1)))
 ctx.prof_enable(False)
 t = time.time(); pi = pcdl.open(ctx, [7], coeffs, C, d, z, w); print("open (unprofiled) %.2f ms" % ((time.time() - t) * 1e3))
+for sw in (1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19):
+    ctx.set_ipa_switch(sw)
+    pcdl.open(ctx, [7], coeffs, C, d, z, w)
+    t = time.time(); pi2 = pcdl.open(ctx, [7], coeffs, C, d, z, w)
+    print("switch 2^%d: open %.2f ms  same proof: %s" % (sw.bit_length() - 1, (time.time() - t) * 1e3, pi2.tolist() == pi.tolist()), flush=True)
+ctx.set_ipa_switch(1 << 16)
 v = ctx.poly_eval(coeffs, z)
 t = time.time(); pcdl.succinct_check(ctx, C, d, z, v, pi); print("succinct_check %.2f ms" % ((time.time() - t) * 1e3))
 t = time.time(); pcdl.check_proof(ctx, C, d, z, v, pi); print("check %.2f ms" % ((time.time() - t) * 1e3), flush=True)
