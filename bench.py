@@ -51,14 +51,16 @@ def main():
     import halo_accumulation_amd as h
     from halo_accumulation_amd import pcdl
     from halo_accumulation_amd.sharded import ShardedMsm, shard_range
-    import orc
 
     n = 1 << args.log_n
     lo, hi = shard_range(n, rank, world)
     # this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
     ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=local_rank)
-    sc_all, _ = orc.rng_scalars(0x48414C4F00000002, n)  # BASELINE.md section 2, seed ...02
-    d_sc = torch.from_numpy(sc_all[lo:hi].view(np.int64).copy()).to(dev)
+    # scalars: SplitMix64 seed ...02, generated on the device by the library's
+    # own generator; this rank's block starts 4*lo draws into the stream
+    GAMMA, MASK = 0x9E3779B97F4A7C15, (1 << 64) - 1
+    d_sc = torch.empty((hi - lo) * 4, dtype=torch.int64, device=dev)
+    ctx.rng_scalars_dev((0x48414C4F00000002 + 4 * lo * GAMMA) & MASK, hi - lo, d_sc.data_ptr())
     # Independent MSMs are pipelined over the context's two workspaces/streams: while MSM k's
     # low-occupancy tail (bucket reduce, D2H of the window sums, host Horner) runs, MSM k+1's
     # recode/sort/accumulate kernels already occupy the CUs.  Every MSM is completed (and, for
@@ -148,6 +150,9 @@ def main():
         # bit-exactness in the same run + CPU baseline (oracle = single-thread port of the arkworks path)
         gs = ctx.read_bases()
         if args.cpu_msms > 0:
+            import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
+            sc_all = np.ascontiguousarray(d_sc.cpu().numpy().view(np.uint64).reshape(n, 4))
+            assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
             t0 = time.perf_counter()
             for _ in range(args.cpu_msms):
                 want = orc.msm_affine(gs, sc_all)
@@ -159,8 +164,10 @@ def main():
                                       "host_cpus": os.cpu_count()}
         if args.open_steps > 0:
             d = n - 1
-            coeffs, s = orc.rng_scalars(0x48414C4F00000003, n)
-            zw, _ = orc.rng_scalars(s, 2)
+            d_co = torch.empty((n + 2) * 4, dtype=torch.int64, device=dev)
+            ctx.rng_scalars_dev(0x48414C4F00000003, n + 2, d_co.data_ptr())  # seed ...03: n coefficients, then z, w
+            co = np.ascontiguousarray(d_co.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
+            coeffs, zw = np.ascontiguousarray(co[:n]), np.ascontiguousarray(co[n:])
             C = pcdl.commit(ctx, coeffs, d)
             pi = pcdl.open(ctx, [1], coeffs, C, d, zw[0])  # warm-up
             v = ctx.poly_eval(coeffs, zw[0])

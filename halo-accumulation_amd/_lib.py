@@ -83,7 +83,9 @@ _SIGS = {
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
+    "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "halo_test_glv_split": (C.c_int, [u64p, C.POINTER(C.c_uint32)]),
     "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
 }
@@ -252,6 +254,12 @@ class Context:
             check(self.lib.halo_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def rng_scalars_dev(self, state: int, n: int, dptr: int) -> int:
+        """Fill device memory with n scalars of the SplitMix64 stream; returns the advanced state."""
+        st = C.c_uint64(state)
+        check(self.lib.halo_rng_scalars_dev(self.h, C.byref(st), n, C.c_void_p(dptr)))
+        return st.value
 
     def set_ipa_switch(self, size):
         check(self.lib.halo_set_ipa_switch(self.h, size))

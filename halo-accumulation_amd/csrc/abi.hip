@@ -501,6 +501,23 @@ int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, lon
     if (launches) *launches = ctx->prof.entries[i].launches;
     return HALO_OK;
 }
+int halo_test_glv_split(const uint64_t xi[4], uint32_t out[16]) {
+    if (!xi || !out) { set_error("glv_split: null pointer"); return HALO_E_ARG; }
+    host::GlvSplit sp = host::glv_split(host::Fr::load(xi));
+    for (int i = 0; i < 5; ++i) { out[i] = sp.s1[i]; out[5 + i] = sp.s2[i]; }
+    out[10] = (uint32_t)sp.e[0]; out[11] = (uint32_t)sp.e[1]; out[12] = (uint32_t)sp.e[2];
+    out[13] = (uint32_t)sp.neg12; out[14] = (uint32_t)sp.nbits; out[15] = 0;
+    return HALO_OK;
+}
+int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out) {
+    HALO_CTX(ctx);
+    if (!rng_state || (n && !d_out)) { set_error("rng_scalars: null pointer"); return HALO_E_ARG; }
+    int rc = rng_scalars_dev(ctx, *rng_state, n, static_cast<uint64_t *>(d_out));
+    if (rc) return rc;
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    *rng_state += 4 * (uint64_t)n * 0x9E3779B97F4A7C15ULL;  // n scalars = 4n draws of the SplitMix64 stream
+    return HALO_OK;
+}
 int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
     if (!out || (k && !pts_jac)) { set_error("point_sum: null pointer"); return HALO_E_ARG; }
     host::Point acc = host::Point::infinity();

@@ -99,28 +99,41 @@ template <int Ka, int Kb>
 HALO_DEV Fq<2> fq_mul(const Fq<Ka> &a, const Fq<Kb> &b) {
     static_assert(Ka * Kb <= 120, "Montgomery product bound: Ka*Kb/128 + 1 must stay < 2");
     uint64_t c[18];
+    uint64_t k29 = M29;
+    asm volatile("" : "+v"(k29));  // a register pair, so it is the free addend of each column's first mad
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc = 0;
+        uint64_t acc = k < 9 ? k29 : 0;  // 2^29 - 1 in the columns the reduction consumes
+        bool first = k < 9;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j >= 0 && j < 9) acc = (uint64_t)a.v[i] * b.v[j] + acc;
+            if (j >= 0 && j < 9) {
+                acc = (uint64_t)a.v[i] * b.v[j] + acc;
+                if (first) { asm volatile("" : "+v"(acc)); first = false; }  // keep k29 as this mad's addend (no reassociation)
+            }
         }
         c[k] = acc;
     }
     c[17] = 0;
+    uint32_t p8 = P29::L[8];
+    asm volatile("" : "+v"(p8));  // keep m * 2^22 on v_mad_u64_u32 (5.3 cycles) instead of a 64-bit shift + add (9.2)
+    // Step i: t = c[i] + carry, m = -t mod 2^29, carry' = (t + m) >> 29 = ceil(t / 2^29).  The low
+    // columns were started at 2^29 - 1 (see above), so here t already holds t + 2^29 - 1: the carry is
+    // a plain shift and m = ~t mod 2^29 -- no "c[i] += m" and no zero-extension of m.
+    uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        uint32_t m = (0u - (uint32_t)c[i]) & M29;
-        c[i] = (uint64_t)m * P29::L[0] + c[i];
+        uint64_t t = c[i] + carry;
+        uint32_t m = (~(uint32_t)t) & M29;
         c[i + 1] = (uint64_t)m * P29::L[1] + c[i + 1];
         c[i + 2] = (uint64_t)m * P29::L[2] + c[i + 2];
         c[i + 3] = (uint64_t)m * P29::L[3] + c[i + 3];
         c[i + 4] = (uint64_t)m * P29::L[4] + c[i + 4];
-        c[i + 8] = (uint64_t)m * P29::L[8] + c[i + 8];
-        c[i + 1] += c[i] >> 29;
+        c[i + 8] = (uint64_t)m * p8 + c[i + 8];
+        carry = t >> 29;
     }
+    c[9] += carry;
     Fq<2> r;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -138,29 +151,45 @@ HALO_DEV Fq<2> fq_sqr(const Fq<Ka> &a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
     uint64_t c[18];
+    uint64_t k29 = M29;
+    asm volatile("" : "+v"(k29));
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc = 0;
+        uint64_t acc = k < 9 ? k29 : 0;
+        bool first = k < 9;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j >= 0 && j < 9 && i < j) acc = (uint64_t)d[i] * a.v[j] + acc;
-            if (j >= 0 && j < 9 && i == j) acc = (uint64_t)a.v[i] * a.v[i] + acc;
+            if (j >= 0 && j < 9 && i < j) {
+                acc = (uint64_t)d[i] * a.v[j] + acc;
+                if (first) { asm volatile("" : "+v"(acc)); first = false; }
+            }
+            if (j >= 0 && j < 9 && i == j) {
+                acc = (uint64_t)a.v[i] * a.v[i] + acc;
+                if (first) { asm volatile("" : "+v"(acc)); first = false; }
+            }
         }
         c[k] = acc;
     }
     c[17] = 0;
+    uint32_t p8 = P29::L[8];
+    asm volatile("" : "+v"(p8));  // keep m * 2^22 on v_mad_u64_u32 (5.3 cycles) instead of a 64-bit shift + add (9.2)
+    // Step i: t = c[i] + carry, m = -t mod 2^29, carry' = (t + m) >> 29 = ceil(t / 2^29).  The low
+    // columns were started at 2^29 - 1 (see above), so here t already holds t + 2^29 - 1: the carry is
+    // a plain shift and m = ~t mod 2^29 -- no "c[i] += m" and no zero-extension of m.
+    uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        uint32_t m = (0u - (uint32_t)c[i]) & M29;
-        c[i] = (uint64_t)m * P29::L[0] + c[i];
+        uint64_t t = c[i] + carry;
+        uint32_t m = (~(uint32_t)t) & M29;
         c[i + 1] = (uint64_t)m * P29::L[1] + c[i + 1];
         c[i + 2] = (uint64_t)m * P29::L[2] + c[i + 2];
         c[i + 3] = (uint64_t)m * P29::L[3] + c[i + 3];
         c[i + 4] = (uint64_t)m * P29::L[4] + c[i + 4];
-        c[i + 8] = (uint64_t)m * P29::L[8] + c[i + 8];
-        c[i + 1] += c[i] >> 29;
+        c[i + 8] = (uint64_t)m * p8 + c[i + 8];
+        carry = t >> 29;
     }
+    c[9] += carry;
     Fq<2> r;
 #pragma unroll
     for (int i = 0; i < 8; i++) {

@@ -1,18 +1,23 @@
 // K1/K2 Pippenger MSM on gfx950 (replaces ark-ec's msm_unchecked as called from
-// group.rs:18-26), K10 batch_to_affine, K11 URS generation (main.rs:18-45) and the primitive
-// test hooks.
+// group.rs:18-26), K10 batch_to_affine, K11 URS generation (main.rs:18-45), the conversions between
+// the ABI's arkworks limbs and the native base-table format, and the primitive test hooks.
 //
 // Pipeline for n points, window c bits, W = ceil(256/c) windows, B = 2^(c-1) buckets each
-// (signed digits, so a point with digit d lands in bucket |d|-1 of its window, negated if d<0):
-//   k_msm_count     : scalar out of Montgomery form (arkworks `into_bigint`), signed-digit
-//                     recode, histogram of bucket sizes          (reads 32 B/scalar, coalesced)
-//   k_scan_*        : exclusive scan of the W*B bucket sizes
-//   k_msm_scatter   : point indices grouped by bucket
-//   k_msm_accumulate: one lane per bucket, XYZZ mixed adds over its index list (gathers 64 B/pt)
-//   k_msm_reduce1/2 : sum_k k*B_k per window with lane-local running sums + wave64 shuffle
-//                     scans (no serial chain longer than ~35 group operations)
-//   host            : Horner over the W window sums (240 doublings are a 60 us job for one
-//                     CPU core and a ~1.5 ms serial chain for one GPU lane)
+// (signed digits: a point with digit d lands in bucket |d|-1 of its window, negated if d < 0):
+//   k_msm_recode      scalar out of Montgomery form (arkworks `into_bigint`), signed-digit recode,
+//                     u16 digits [window][i]                      (32 B in per scalar, coalesced)
+//   k_msm_hist        per (window, chunk) histogram with all 2^(c-1) counters in LDS
+//   k_msm_colsum      bucket sizes + per-chunk prefixes; k_scan_*: exclusive scan of the sizes
+//   k_msm_scatter     point indices grouped by bucket (LDS cursors)
+//   k_msm_ntasks/_task_meta/_task_bins/_task_order
+//                     buckets cut into tasks of <= kmax entries, tasks sorted by decreasing length
+//   k_msm_accumulate  one lane per task: XYZZ mixed adds over its index list (dominant kernel)
+//   k_msm_combine_*   partials of multi-task buckets folded into the bucket value
+//   k_msm_reduce1/2   sum_k k*B_k per window: lane-local running sums + wave64 shuffle scans
+//   host              Horner over the W window sums (240 doublings are a 60 us job for one CPU
+//                     core and a > 1 ms serial chain for one GPU lane)
+// msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
+// overlap on the context's slots (workspace + stream each).
 #include "curve.cuh"
 #include "internal.hpp"
 

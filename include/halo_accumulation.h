@@ -143,6 +143,10 @@ int halo_prof_reset(halo_ctx *ctx);
 /* number of distinct kernels seen; name/total ms/launch count of entry i */
 int halo_prof_count(halo_ctx *ctx);
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
+/* n uniform scalars (Montgomery limbs) of the SplitMix64 stream, written to DEVICE memory: the
+ * synthetic-input generator of the benchmarks (element i = draws 4i+1..4i+4 after *rng_state,
+ * little-endian, reduced mod r); *rng_state advances as a sequential stream would */
+int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out);
 /* sum of k Jacobian points in index order, on the host (combine step of the sharded MSM) */
 int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]);
 /* IPA tuning: key size at which halo_ipa_* stops folding G and switches to MSMs over the fixed
@@ -152,6 +156,8 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 int halo_set_window_bits(halo_ctx *ctx, int c);
 
 /* ---- primitive hooks used by the parity tests (elementwise over n) ----------------------- */
+/* host-only: GLV split of the fold scalar (host_math.hpp): out = s1[5] | s2[5] | e[3] | neg12 | nbits | 0 */
+int halo_test_glv_split(const uint64_t xi[4], uint32_t out[16]);
 int halo_test_field_op(halo_ctx *ctx, int field /*0 Fq, 1 Fr*/, int op /*0 mul,1 add,2 sub,3 inv,4 from_mont,5 to_mont*/,
                        const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 /* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs) */

@@ -294,3 +294,13 @@ def test_msm_pipelined_slots_agree(ctx1m):
             assert ctx1m.msm_dev_end(slot).tolist() == want[slot]
     with pytest.raises(Exception):
         ctx1m.msm_dev_end(0)  # nothing in flight
+
+
+def test_device_rng_matches_stream(ctx16k):
+    """halo_rng_scalars_dev == the sequential SplitMix64 stream the oracle and the tests use."""
+    import torch
+    n = 1000
+    d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    st = ctx16k.rng_scalars_dev(0x48414C4F00000002, n, d.data_ptr())
+    want, st_ref = orc.rng_scalars(0x48414C4F00000002, n)
+    assert d.cpu().numpy().view(np.uint64).reshape(n, 4).tolist() == want.tolist() and st == st_ref
