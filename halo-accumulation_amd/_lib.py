@@ -41,6 +41,7 @@ _SIGS = {
     "halo_device_count": (C.c_int, []),
     "halo_ctx_create": (C.c_int, [C.c_int, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_create_urs": (C.c_int, [C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_create_urs_strided": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_destroy": (None, [C.c_void_p]),
     "halo_ctx_size": (C.c_size_t, [C.c_void_p]),
     "halo_ctx_read_bases": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p]),
@@ -60,6 +61,13 @@ _SIGS = {
     "halo_h_eval_batch": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_h_accumulate": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, u64p]),
     "halo_ipa_begin": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, C.POINTER(C.c_void_p)]),
+    "halo_ipa_begin_strided": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "halo_ipa_begin_vectors": (C.c_int, [C.c_void_p, C.c_size_t, u64p, u64p, C.POINTER(C.c_void_p)]),
+    "halo_ipa_dot_cz": (C.c_int, [C.c_void_p, u64p]),
+    "halo_ipa_round_lr_partial": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "halo_ipa_finish_z": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "halo_open_start": (C.c_int, [u64p, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_open_combine": (C.c_int, [u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]),
     "halo_ipa_round_lr": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "halo_ipa_round_fold": (C.c_int, [C.c_void_p, u64p, u64p]),
     "halo_ipa_finish": (C.c_int, [C.c_void_p, u64p, u64p]),
@@ -131,12 +139,14 @@ def check(rc: int) -> None:
 class Context:
     """A commitment key resident on one GPU (consts.rs: N, GS)."""
 
-    def __init__(self, bases=None, *, urs_n: int | None = None, first_index: int = 2, device: int = 0):
+    def __init__(self, bases=None, *, urs_n: int | None = None, first_index: int = 2, stride: int = 1, device: int = 0):
         lib = load()
         h = C.c_void_p()
         if bases is not None:
             bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
             check(lib.halo_ctx_create(device, ptr(bases), bases.shape[0], C.byref(h)))
+        elif stride != 1:
+            check(lib.halo_ctx_create_urs_strided(device, first_index, stride, int(urs_n), C.byref(h)))
         else:
             check(lib.halo_ctx_create_urs(device, first_index, int(urs_n), C.byref(h)))
         self.h = h
@@ -286,11 +296,37 @@ class Context:
 class Ipa:
     """Device-resident state of pcdl::open's halving loop (pcdl.rs:183-231)."""
 
-    def __init__(self, ctx: Context, n: int, coeffs, z):
+    def __init__(self, ctx: Context, n: int, coeffs, z, *, stride: int = 1, offset: int = 0, z_vec=None):
+        """Default: c = coeffs zero-padded, z-vector = powers of z.  stride/offset: the cyclic shard
+        z^(offset + j*stride).  z_vec: explicit vectors (coeffs and z_vec both of length n)."""
         coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
         h = C.c_void_p()
-        check(ctx.lib.halo_ipa_begin(ctx.h, n, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)), C.byref(h)))
+        if z_vec is not None:
+            z_vec = np.ascontiguousarray(z_vec, dtype=np.uint64).reshape(-1, 4)
+            assert coeffs.shape[0] == n == z_vec.shape[0]
+            check(ctx.lib.halo_ipa_begin_vectors(ctx.h, n, ptr(coeffs), ptr(z_vec), C.byref(h)))
+        elif stride != 1 or offset != 0:
+            check(ctx.lib.halo_ipa_begin_strided(ctx.h, n, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)),
+                                                 stride, offset, C.byref(h)))
+        else:
+            check(ctx.lib.halo_ipa_begin(ctx.h, n, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)), C.byref(h)))
         self.h, self.ctx = h, ctx
+
+    def dot_cz(self):
+        out = np.zeros(4, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_dot_cz(self.h, ptr(out)))
+        return out
+
+    def round_lr_partial(self):
+        """-> one record L 12 | R 12 | dot_l 4 | dot_r 4 (no H' terms)"""
+        rec = np.zeros(32, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_round_lr_partial(self.h, ptr(rec[:12]), ptr(rec[12:24]), ptr(rec[24:])))
+        return rec
+
+    def finish_z(self):
+        U, c, z0 = np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_finish_z(self.h, ptr(U), ptr(c), ptr(z0)))
+        return U, c, z0
 
     def round_lr(self, H_prime):
         L, R = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
@@ -318,6 +354,25 @@ class Ipa:
             self.close()
         except Exception:
             pass
+
+
+def open_start(Cm, z, v_parts):
+    """v = sum of the shards' <c, z>; xi_0 = rho_0(C, z, v); H' = xi_0 H"""
+    v_parts = np.ascontiguousarray(v_parts, dtype=np.uint64).reshape(-1, 4)
+    v, xi, Hp = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    check(load().halo_open_start(ptr(np.ascontiguousarray(Cm, dtype=np.uint64)), ptr(np.ascontiguousarray(z, dtype=np.uint64)), ptr(v_parts),
+                                 v_parts.shape[0], ptr(v), ptr(xi), ptr(Hp)))
+    return v, xi, Hp
+
+
+def open_combine(parts, Hp, xi_prev):
+    """parts (P, 32) in rank order -> L, R, xi_next, xi_next^-1"""
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 32)
+    L, R = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    xi, xi_inv = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    check(load().halo_open_combine(ptr(parts), parts.shape[0], ptr(np.ascontiguousarray(Hp, dtype=np.uint64)),
+                                   ptr(np.ascontiguousarray(xi_prev, dtype=np.uint64)), ptr(L), ptr(R), ptr(xi), ptr(xi_inv)))
+    return L, R, xi, xi_inv
 
 
 def point_sum(pts_jac):

@@ -113,7 +113,14 @@ static int ipa_enter_nofold(halo_ipa *st) {
     return HALO_OK;
 }
 
+static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z_base, const host::Fr *z_scale,
+                             const uint64_t *d_z_vec, halo_ipa **out);
 int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out) {
+    return ipa_begin_general(ctx, n, d_coeffs_padded, z, nullptr, nullptr, out);
+}
+// z vector: d_z_vec if given, else z_base^j (times *z_scale if given)
+static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z_base, const host::Fr *z_scale,
+                             const uint64_t *d_z_vec, halo_ipa **out) {
     halo_ipa *st = new (std::nothrow) halo_ipa();
     if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
     st->ctx = ctx;
@@ -127,7 +134,14 @@ int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, cons
             hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
         }
-        rc = fr_powers(ctx, z, n, st->d_z);
+        if (d_z_vec) {
+            if (hipMemcpyAsync(st->d_z, d_z_vec, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
+            }
+        } else {
+            rc = fr_powers(ctx, z_base, n, st->d_z);
+            if (!rc && z_scale) rc = fr_scale(ctx, st->d_z, n, *z_scale);
+        }
         if (rc) break;
         size_t M = n < kNoFoldSize ? n : kNoFoldSize;
         if (hipMalloc(&st->d_s, M * 32) != hipSuccess || hipMalloc(&st->d_s2, M * 32) != hipSuccess ||
@@ -176,7 +190,18 @@ int halo_ctx_create_urs(int device, uint64_t first_index, size_t n, halo_ctx **o
     halo_ctx *ctx = new (std::nothrow) halo_ctx();
     if (!ctx) { set_error("out of host memory"); return HALO_E_ARG; }
     int rc = ctx_alloc_common(ctx, device, n);
-    if (rc == HALO_OK) rc = urs_generate(ctx, first_index, n, ctx->d_bases);
+    if (rc == HALO_OK) rc = urs_generate(ctx, first_index, 1, n, ctx->d_bases);
+    if (rc != HALO_OK) { halo_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return HALO_OK;
+}
+
+int halo_ctx_create_urs_strided(int device, uint64_t first_index, uint64_t stride, size_t n, halo_ctx **out) {
+    if (!out || stride == 0) { set_error("ctx_create_urs_strided: bad argument"); return HALO_E_ARG; }
+    halo_ctx *ctx = new (std::nothrow) halo_ctx();
+    if (!ctx) { set_error("out of host memory"); return HALO_E_ARG; }
+    int rc = ctx_alloc_common(ctx, device, n);
+    if (rc == HALO_OK) rc = urs_generate(ctx, first_index, stride, n, ctx->d_bases);
     if (rc != HALO_OK) { halo_ctx_destroy(ctx); return rc; }
     *out = ctx;
     return HALO_OK;
@@ -376,17 +401,87 @@ int halo_ipa_begin(halo_ctx *ctx, size_t n, const uint64_t *coeffs, size_t len, 
     return ipa_begin_dev(ctx, n, ctx->d_tmp_a, host::Fr::load(z), out);
 }
 
+static host::Fr fr_pow_u64(const host::Fr &z, uint64_t e) {
+    uint64_t ex[4] = {e, 0, 0, 0};
+    return z.pow(ex);
+}
+
+int halo_ipa_begin_strided(halo_ctx *ctx, size_t n_local, const uint64_t *coeffs_local, size_t len, const uint64_t z[4], uint64_t stride,
+                           uint64_t offset, halo_ipa **out) {
+    HALO_CTX(ctx);
+    if (!out || !z || (len && !coeffs_local) || stride == 0) { set_error("ipa_begin_strided: bad argument"); return HALO_E_ARG; }
+    if (!is_pow2(n_local)) { set_error("ipa_begin: n is not a power of two"); return HALO_E_ASSERT; }
+    if (n_local > ctx->n) { set_error("ipa_begin: n exceeds the commitment key (d <= D)"); return HALO_E_ASSERT; }
+    if (len > n_local) { set_error("ipa_begin: more coefficients than n (p.degree() <= d)"); return HALO_E_ASSERT; }
+    HALO_HIP(hipMemsetAsync(ctx->d_tmp_a, 0, n_local * 32, ctx->stream));
+    int rc = upload(ctx, ctx->d_tmp_a, coeffs_local, len * 4);
+    if (rc) return rc;
+    host::Fr zz = host::Fr::load(z);
+    host::Fr base = fr_pow_u64(zz, stride), scale = fr_pow_u64(zz, offset);  // z^(offset + j * stride)
+    return ipa_begin_general(ctx, n_local, ctx->d_tmp_a, base, &scale, nullptr, out);
+}
+
+int halo_ipa_begin_vectors(halo_ctx *ctx, size_t n, const uint64_t *c_vec, const uint64_t *z_vec, halo_ipa **out) {
+    HALO_CTX(ctx);
+    if (!out || (n && (!c_vec || !z_vec))) { set_error("ipa_begin_vectors: null pointer"); return HALO_E_ARG; }
+    if (!is_pow2(n)) { set_error("ipa_begin: n is not a power of two"); return HALO_E_ASSERT; }
+    if (n > ctx->n) { set_error("ipa_begin: n exceeds the commitment key (d <= D)"); return HALO_E_ASSERT; }
+    int rc = upload(ctx, ctx->d_tmp_a, c_vec, n * 4);
+    if (!rc) rc = upload(ctx, ctx->d_tmp_b, z_vec, n * 4);
+    if (rc) return rc;
+    return ipa_begin_general(ctx, n, ctx->d_tmp_a, host::Fr::one(), nullptr, ctx->d_tmp_b, out);
+}
+
+int halo_ipa_dot_cz(halo_ipa *st, uint64_t out[4]) {
+    if (!st || !out) { set_error("null ipa state"); return HALO_E_ARG; }
+    halo_ctx *ctx = st->ctx;
+    HALO_CTX(ctx);
+    host::Fr r[2];
+    int rc = fr_dot2(ctx, st->d_c, st->d_z, nullptr, nullptr, st->m, r);
+    if (rc) return rc;
+    r[0].store(out);
+    return HALO_OK;
+}
+
+static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp, host::Point *Rp);
+
+int halo_ipa_round_lr_partial(halo_ipa *st, uint64_t L[12], uint64_t R[12], uint64_t dots_out[8]) {
+    if (!st || !L || !R || !dots_out) { set_error("null ipa state"); return HALO_E_ARG; }
+    halo_ctx *ctx = st->ctx;
+    HALO_CTX(ctx);
+    host::Fr dots[2];
+    host::Point Lp, Rp;
+    int rc = ipa_round_lr_points(st, dots, &Lp, &Rp);
+    if (rc) return rc;
+    Lp.store_normalized(L);
+    Rp.store_normalized(R);
+    dots[0].store(dots_out);
+    dots[1].store(dots_out + 4);
+    return HALO_OK;
+}
+
 int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], uint64_t R[12]) {
     if (!st) { set_error("null ipa state"); return HALO_E_ARG; }
     halo_ctx *ctx = st->ctx;
     HALO_CTX(ctx);
+    host::Fr dots[2];
+    host::Point Lp, Rp, Hp = host::Point::load(H_prime);
+    int rc = ipa_round_lr_points(st, dots, &Lp, &Rp);
+    if (rc) return rc;
+    (Lp + Hp.mul(dots[0])).store_normalized(L);
+    (Rp + Hp.mul(dots[1])).store_normalized(R);
+    return HALO_OK;
+}
+
+// <c_r, G_l>, <c_l, G_r> and the two dot products of one round, without the H' terms
+static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_out, host::Point *Rp_out) {
+    halo_ctx *ctx = st->ctx;
     if (st->m < 2) { set_error("ipa_round_lr: no rounds left"); return HALO_E_ARG; }
     size_t m = st->m / 2;
-    host::Fr dots[2];
     // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207)
     int rc = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
     if (rc) return rc;
-    host::Point Hp = host::Point::load(H_prime), Lp, Rp;
+    host::Point Lp, Rp;
     // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; slot 1's stream first waits
     // for everything queued on stream 0 (the previous round's folds)
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
@@ -409,8 +504,8 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     int rc2 = msm_finish(ctx, 1, &Rp);
     if (rc) return rc;
     if (rc2) return rc2;
-    (Lp + Hp.mul(dots[0])).store_normalized(L);
-    (Rp + Hp.mul(dots[1])).store_normalized(R);
+    *Lp_out = Lp;
+    *Rp_out = Rp;
     return HALO_OK;
 }
 
@@ -461,6 +556,13 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     return HALO_OK;
 }
 
+int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4]) {
+    int rc = halo_ipa_finish(st, U, c);
+    if (rc) return rc;
+    if (!z0) { set_error("ipa_finish_z: null pointer"); return HALO_E_ARG; }
+    return download(st->ctx, z0, st->d_z, 4);
+}
+
 void halo_ipa_destroy(halo_ipa *st) {
     if (!st) return;
     if (st->ctx) {
@@ -501,6 +603,47 @@ int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, lon
     if (launches) *launches = ctx->prof.entries[i].launches;
     return HALO_OK;
 }
+// ---- host steps of a sharded pcdl::open (halo-accumulation_amd/sharded.py) ---------------------
+int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, size_t P, uint64_t v_out[4], uint64_t xi0[4],
+                    uint64_t Hp_out[12]) {
+    if (!C || !z || !v_parts || !v_out || !xi0 || !Hp_out || P == 0) { set_error("open_start: bad argument"); return HALO_E_ARG; }
+    host::Fr v = host::Fr::zero();
+    for (size_t i = 0; i < P; ++i) v = v + host::Fr::load(v_parts + 4 * i);  // p(z) = sum of the shards' <c, z>
+    host::Transcript t;
+    t.point(host::Point::load(C)); t.scalar(host::Fr::load(z)); t.scalar(v);
+    host::Fr x0 = t.finish(0);  // pcdl.rs:180
+    uint64_t S[12], H[12];
+    halo_public_points(S, H);
+    host::Point::load(H).mul(x0).store_normalized(Hp_out);  // pcdl.rs:181
+    v.store(v_out);
+    x0.store(xi0);
+    return HALO_OK;
+}
+// parts: P records of L 12 | R 12 | dot_l 4 | dot_r 4 in rank order
+int halo_open_combine(const uint64_t *parts, size_t P, const uint64_t Hp[12], const uint64_t xi_prev[4], uint64_t L[12], uint64_t R[12],
+                      uint64_t xi[4], uint64_t xi_inv[4]) {
+    if (!parts || !Hp || !xi_prev || !L || !R || !xi || !xi_inv || P == 0) { set_error("open_combine: bad argument"); return HALO_E_ARG; }
+    host::Point Lp = host::Point::infinity(), Rp = host::Point::infinity(), H = host::Point::load(Hp);
+    host::Fr dl = host::Fr::zero(), dr = host::Fr::zero();
+    for (size_t i = 0; i < P; ++i) {
+        const uint64_t *r = parts + 32 * i;
+        Lp = Lp + host::Point::load(r);
+        Rp = Rp + host::Point::load(r + 12);
+        dl = dl + host::Fr::load(r + 24);
+        dr = dr + host::Fr::load(r + 28);
+    }
+    Lp = (Lp + H.mul(dl)).normalized();  // pcdl.rs:204
+    Rp = (Rp + H.mul(dr)).normalized();  // pcdl.rs:208
+    host::Transcript t;
+    t.scalar(host::Fr::load(xi_prev)); t.point(Lp); t.point(Rp);
+    host::Fr x = t.finish(0);  // pcdl.rs:212
+    if (x.is_zero()) { set_error("open: challenge is zero (inverse().unwrap())"); return HALO_E_ASSERT; }
+    Lp.store(L); Rp.store(R);
+    x.store(xi);
+    x.inv().store(xi_inv);
+    return HALO_OK;
+}
+
 int halo_test_glv_split(const uint64_t xi[4], uint32_t out[16]) {
     if (!xi || !out) { set_error("glv_split: null pointer"); return HALO_E_ARG; }
     host::GlvSplit sp = host::glv_split(host::Fr::load(xi));

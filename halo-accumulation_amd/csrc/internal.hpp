@@ -121,7 +121,7 @@ int msm_finish(halo_ctx *ctx, int slot, host::Point *out);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
 // bases: native affine table (20 words per point)
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);
-int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out_native);
+int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n, uint32_t *d_out_native);
 int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac_words, size_t n, uint32_t *d_out_native);
 int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t *d_out);
 int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
@@ -135,6 +135,8 @@ int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, cons
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
             host::Fr out[2]);
 int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out);
+// d_v[i] *= a
+int fr_scale(halo_ctx *ctx, uint64_t *d_v, size_t n, const host::Fr &a);
 int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host::Fr &z, host::Fr *out);
 // d_out[k] (+)= scale * prod_{bit i of k} xis[lg_n - i]
 int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr &scale, bool accumulate, uint64_t *d_out);

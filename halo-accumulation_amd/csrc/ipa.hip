@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256) void k_nofold_s_update(const uint64_t *__restr
     fe_store(s_out + 4 * (size_t)i, v);
 }
 
+// v[i] *= a   (z-powers of a cyclic shard: z^(r + jP) = z^r * (z^P)^j)
+__global__ __launch_bounds__(256) void k_scale(uint64_t *__restrict__ v, uint32_t n, FeArg aarg) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    fe_store(v + 4 * (size_t)i, fe_mul<FrCfg>(fe_load(v + 4 * (size_t)i), from_arg(aarg)));
+}
+
 // ================================================================== host launchers
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
@@ -459,6 +466,13 @@ int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_
 int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out) {
     HALO_LAUNCH(ctx, "k_nofold_s_update", k_nofold_s_update, dim3((unsigned)((2 * len + 255) / 256)), dim3(256), 0, d_s_in, (uint32_t)len,
                 to_arg(xi), d_s_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int fr_scale(halo_ctx *ctx, uint64_t *d_v, size_t n, const host::Fr &a) {
+    if (n == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_scale", k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_v, (uint32_t)n, to_arg(a));
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

@@ -574,12 +574,12 @@ static const std::vector<uint64_t> &urs_table() {
     return tbl;
 }
 
-int urs_generate(halo_ctx *ctx, uint64_t first_index, size_t n, uint32_t *d_out) {
+int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
     const std::vector<uint64_t> &tbl = urs_table();
     std::vector<uint64_t> canon(4 * n);
     for (size_t i = 0; i < n; ++i) {
-        host::Fr s = host::urs_scalar(first_index + i).from_mont();
+        host::Fr s = host::urs_scalar(first_index + (uint64_t)i * stride).from_mont();
         s.store(&canon[4 * i]);
     }
     uint64_t *d_tbl = nullptr, *d_canon = nullptr;

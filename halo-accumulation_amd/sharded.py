@@ -59,3 +59,78 @@ class ShardedMsm:
         self.dist.all_gather_into_tensor(self._recv, self._send)
         pts = self._recv.cpu().numpy().view(np.uint64).reshape(self.world, 12)
         return self.sum_fn(pts)
+
+
+# Fq Montgomery one: the X, Y of the library's normalised point at infinity (1, 1, 0)
+_FQ_ONE = np.array([0x34786D38FFFFFFFD, 0x992C350BE41914AD, 0xFFFFFFFFFFFFFFFF, 0x3FFFFFFFFFFFFFFF], dtype=np.uint64)
+
+
+class ShardedOpen:
+    """pcdl::open (non-hiding branch, pcdl.rs:120-242) with G, c and the z-powers sharded cyclically:
+    element i lives on rank i mod P.  The fold pairs j with j + m (m = n/2, n/4, ...), so both partners
+    stay on one rank for every round with m >= P: a round costs one all-gather of P x 256 bytes
+    (partial L, R and the two partial dot products) and NO vector exchange.  After lg(n/P) rounds each
+    rank holds one element of G, c, z; they are gathered (P x 160 bytes) and the last lg P rounds run
+    replicated on every rank.  Every rank derives the same challenges and returns the same proof, which is
+    bit-identical to the single-GPU halo_pcdl_open.
+
+    allgather(arr) -> (P, len(arr)) uint64 is supplied by the caller (torch.distributed over RCCL or gloo).
+    """
+
+    def __init__(self, lib, rank: int, world: int, allgather, device: int = 0):
+        assert world & (world - 1) == 0, "world size must be a power of two"
+        self.lib, self.rank, self.world, self.allgather, self.device = lib, rank, world, allgather, device
+        self.ctx = None
+
+    def load_key(self, n: int, first_index: int = 2):
+        """This rank's cyclic shard of the key: G_{r + jP} = hash(first_index + r + jP)  (main.rs:35-45)."""
+        assert n % self.world == 0
+        self.n = n
+        self.ctx = self.lib.Context(urs_n=n // self.world, first_index=first_index + self.rank, stride=self.world, device=self.device)
+        return self.ctx
+
+    def _rounds(self, ipa, count, Hp, xi, Ls, Rs, world):
+        for _ in range(count):
+            rec = ipa.round_lr_partial()
+            parts = self.allgather(rec) if world > 1 else rec[None]
+            L, R, xi, xi_inv = self.lib.open_combine(parts, Hp, xi)
+            Ls.append(L)
+            Rs.append(R)
+            ipa.round_fold(xi, xi_inv)
+        return xi
+
+    def open(self, coeffs_local, Cm, z):
+        """coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).  -> (proof, v)"""
+        P, nl = self.world, self.n // self.world
+        lg_n = self.n.bit_length() - 1
+        ipa = self.lib.Ipa(self.ctx, nl, coeffs_local, z, stride=P, offset=self.rank)
+        v_part = ipa.dot_cz()  # this shard's share of p(z)
+        v_parts = self.allgather(v_part) if P > 1 else v_part[None]
+        v, xi, Hp = self.lib.open_start(Cm, z, v_parts)
+        Ls, Rs = [], []
+        xi = self._rounds(ipa, nl.bit_length() - 1, Hp, xi, Ls, Rs, P)
+        U, c, z0 = ipa.finish_z()
+        ipa.close()
+        if P > 1:
+            rec = self.allgather(np.concatenate([U, c, z0]))  # (P, 20): the P remaining elements in index order
+            bases = np.zeros((P, 8), dtype=np.uint64)
+            for i in range(P):
+                if rec[i, 8:12].any():  # Z = 1: normalised affine; Z = 0: infinity stays (0, 0)
+                    bases[i] = rec[i, :8]
+            small = self.lib.Context(bases, device=self.device)
+            ipa2 = self.lib.Ipa(small, P, np.ascontiguousarray(rec[:, 12:16]), None, z_vec=np.ascontiguousarray(rec[:, 16:20]))
+            self._rounds(ipa2, P.bit_length() - 1, Hp, xi, Ls, Rs, 1)
+            U, c = ipa2.finish()
+            ipa2.close()
+            small.close()
+        proof = np.zeros(self.lib.load().halo_proof_words(lg_n), dtype=np.uint64)
+        proof[1] = lg_n
+        for i in range(lg_n):
+            proof[2 + 12 * i: 14 + 12 * i] = Ls[i]
+            proof[2 + 12 * lg_n + 12 * i: 14 + 12 * lg_n + 12 * i] = Rs[i]
+        o = 2 + 24 * lg_n
+        proof[o: o + 12] = U
+        proof[o + 12: o + 16] = c
+        proof[o + 16: o + 20] = _FQ_ONE  # C_bar = None: the point at infinity
+        proof[o + 20: o + 24] = _FQ_ONE
+        return proof, v

@@ -51,6 +51,8 @@ int halo_ctx_create(int device, const uint64_t *bases_affine, size_t n, halo_ctx
 /* Derive G_i = [SHA3-256(genesis || LE64(first_index + i)) mod r] * (-1, 2) on the device
  * (main.rs:18-45; GS[i] of consts.rs is first_index = 2).  Hashing on host, scalar-mul in HIP. */
 int halo_ctx_create_urs(int device, uint64_t first_index, size_t n, halo_ctx **out);
+/* same with G_j = hash(first_index + j * stride): a rank's cyclic shard of the key (stride = world size) */
+int halo_ctx_create_urs_strided(int device, uint64_t first_index, uint64_t stride, size_t n, halo_ctx **out);
 void halo_ctx_destroy(halo_ctx *ctx);
 size_t halo_ctx_size(const halo_ctx *ctx);
 /* copy bases [off, off+n) back to the host (n x 8 limbs) */
@@ -95,6 +97,25 @@ int halo_h_accumulate(halo_ctx *ctx, const uint64_t *h0, const uint64_t *xis, co
 /* ---- pcdl.rs:183-231: the IPA halving loop, state device resident ------------------------ */
 /* G = GS[0..n), c = coeffs zero-padded to n, z-powers of z (pcdl.rs:183-186) */
 int halo_ipa_begin(halo_ctx *ctx, size_t n, const uint64_t *coeffs, size_t len, const uint64_t z[4], halo_ipa **out);
+/* ---- sharded open: rank r of P holds the cyclic shard i = r (mod P) of G, c, z-powers ----
+ * local state over n_local = n / P elements with z-vector z^(offset + j * stride) */
+int halo_ipa_begin_strided(halo_ctx *ctx, size_t n_local, const uint64_t *coeffs_local, size_t len, const uint64_t z[4],
+                           uint64_t stride, uint64_t offset, halo_ipa **out);
+/* state from explicit c and z vectors (the last lg P rounds on the gathered P elements) */
+int halo_ipa_begin_vectors(halo_ctx *ctx, size_t n, const uint64_t *c_vec, const uint64_t *z_vec, halo_ipa **out);
+/* <c, z> of the current state (a shard's share of p(z) before the first round) */
+int halo_ipa_dot_cz(halo_ipa *st, uint64_t out[4]);
+/* this shard's <c_r, G_l>, <c_l, G_r> (no H' term) and dots = <c_r, z_l> | <c_l, z_r> */
+int halo_ipa_round_lr_partial(halo_ipa *st, uint64_t L[12], uint64_t R[12], uint64_t dots[8]);
+/* halo_ipa_finish plus z[0] */
+int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4]);
+/* host steps between collectives: v = sum of the shards' <c, z>, xi_0 = rho_0(C, z, v), H' = xi_0 H (pcdl.rs:135,180-181) */
+int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, size_t P, uint64_t v_out[4], uint64_t xi0[4],
+                    uint64_t Hp_out[12]);
+/* parts = P records (L 12 | R 12 | dot_l 4 | dot_r 4) in rank order -> L, R with the H' terms, the next
+ * challenge rho_0(xi_prev, L, R) and its inverse (pcdl.rs:203-213) */
+int halo_open_combine(const uint64_t *parts, size_t P, const uint64_t Hp[12], const uint64_t xi_prev[4], uint64_t L[12], uint64_t R[12],
+                      uint64_t xi[4], uint64_t xi_inv[4]);
 /* L = <c_r, G_l> + <c_r, z_l> H', R = <c_l, G_r> + <c_l, z_r> H'   (pcdl.rs:203-208) */
 int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], uint64_t R[12]);
 /* G, c, z folds with the challenge the host hashed from (xi_prev, L, R)   (pcdl.rs:216-224) */

@@ -4,8 +4,12 @@ blob-for-blob equality with the CPU restatement on the same seeded inputs."""
 import numpy as np
 import pytest
 
+import os
+
 import orc
 import pallas_model as pm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -268,3 +272,84 @@ def test_acc_chain_2_20_completeness(hal):
             A.decider(c, bad)
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ sharded open
+def _sharded_worker(rank, world, port, n, q):
+    import os, sys
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd import pcdl
+    from halo_accumulation_amd.sharded import ShardedOpen
+    import orc
+
+    def allgather(arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
+        out = torch.empty(world * t.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, t)
+        return out.numpy().view(np.uint64).reshape(world, -1)
+
+    coeffs, s = orc.rng_scalars(0x48414C4F00000003, n - 3)   # every rank derives the same polynomial
+    z, _ = orc.rng_scalars(s, 1)
+    full = np.zeros((n, 4), dtype=np.uint64); full[: n - 3] = coeffs
+    so = ShardedOpen(h._lib, rank, world, allgather)
+    so.load_key(n)
+    if rank == 0:
+        ref = h._lib.Context(urs_n=n)
+        C = pcdl.commit(ref, coeffs, n - 1)
+        want = pcdl.open(ref, [1], coeffs, C, n - 1, z[0])
+        Cs = torch.from_numpy(C.view(np.int64).copy())
+    else:
+        Cs = torch.zeros(12, dtype=torch.int64)
+    dist.broadcast(Cs, 0)
+    C = Cs.numpy().view(np.uint64)
+    proof, v = so.open(np.ascontiguousarray(full[rank::world]), C, z[0])
+    ok = True
+    if rank == 0:
+        ok = proof.tolist() == want.tolist()
+        pcdl.check_proof(ref, C, n - 1, z[0], v, proof)
+        ref.close()
+    q.put((rank, ok, proof.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1 << 10), (4, 1 << 17)])
+def test_sharded_open_two_and_four_ranks_on_one_gpu(world, n):
+    """Ranks share the single GPU of the test box and talk over gloo: the sharded open must return, on
+    every rank, the proof the single-GPU pcdl::open returns."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(pr == res[0][2] for _, _, pr in res)
+
+
+def test_sharded_open_world_one_is_plain_open(hal, ctx):
+    from halo_accumulation_amd import pcdl
+    from halo_accumulation_amd.sharded import ShardedOpen
+    n = 512
+    coeffs, s = orc.rng_scalars(77, n)
+    z, _ = orc.rng_scalars(s, 1)
+    C = pcdl.commit(ctx, coeffs, n - 1)
+    so = ShardedOpen(hal._lib, 0, 1, None)
+    so.load_key(n)
+    proof, v = so.open(coeffs, C, z[0])
+    assert proof.tolist() == pcdl.open(ctx, [1], coeffs, C, n - 1, z[0]).tolist()
+    assert v.tolist() == ctx.poly_eval(coeffs, z[0]).tolist()
