@@ -93,9 +93,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_steps(3 * args.depth)  # untimed: every slot allocates its workspace and captures its launch graph
     out = run_steps(args.warmup)
-    ctx.prof_enable(2)  # HIP events around the dominant kernel only, on the stream it is launched on
-    ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
@@ -105,10 +104,18 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    # Kernel durations for the roofline: HIP events on the stream each kernel is launched on, in two
+    # extra passes of the same loop right after the timed region (the event brackets need individual
+    # launches, the timed region replays the launch sequence as a hipGraph): (a) as timed, several
+    # MSMs in flight -- kernels of different slots time-share the CUs and every duration stretches;
+    # (b) one MSM in flight: the kernel by itself, which is what a roofline fraction is about.
+    ctx.prof_enable(2)
+    ctx.prof_reset()
+    barrier()
+    run_steps(min(args.steps, 8))
+    barrier()
     prof = ctx.prof()
-    # The roofline is a statement about the kernel itself: with several MSMs in flight the kernels of
-    # different slots time-share the CUs and every per-launch duration stretches, so the dominant
-    # kernel is also timed un-overlapped (one MSM in flight), with the same HIP-event brackets.
     cfg["depth"], solo_steps = 1, min(args.steps, 8)
     ctx.prof_reset()
     barrier()

@@ -93,6 +93,7 @@ _SIGS = {
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "halo_set_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_test_glv_split": (C.c_int, [u64p, C.POINTER(C.c_uint32)]),
     "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
@@ -270,6 +271,9 @@ class Context:
         st = C.c_uint64(state)
         check(self.lib.halo_rng_scalars_dev(self.h, C.byref(st), n, C.c_void_p(dptr)))
         return st.value
+
+    def set_graphs(self, on: bool):
+        check(self.lib.halo_set_graphs(self.h, int(on)))
 
     def set_ipa_switch(self, size):
         check(self.lib.halo_set_ipa_switch(self.h, size))

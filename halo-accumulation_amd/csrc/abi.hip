@@ -468,8 +468,9 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     host::Point Lp, Rp, Hp = host::Point::load(H_prime);
     int rc = ipa_round_lr_points(st, dots, &Lp, &Rp);
     if (rc) return rc;
-    (Lp + Hp.mul(dots[0])).store_normalized(L);
-    (Rp + Hp.mul(dots[1])).store_normalized(R);
+    if (!st->hp_table.matches(Hp)) st->hp_table = host::FixedBaseTable(Hp);  // H' is fixed for a whole open
+    (Lp + st->hp_table.mul(dots[0])).store_normalized(L);
+    (Rp + st->hp_table.mul(dots[1])).store_normalized(R);
     return HALO_OK;
 }
 
@@ -666,6 +667,11 @@ int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
     host::Point acc = host::Point::infinity();
     for (size_t i = 0; i < k; ++i) acc = acc + host::Point::load(pts_jac + 12 * i);  // fixed rank order 0..k-1
     acc.store_normalized(out);
+    return HALO_OK;
+}
+int halo_set_graphs(halo_ctx *ctx, int on) {
+    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
+    ctx->use_graphs = on != 0;
     return HALO_OK;
 }
 int halo_set_ipa_switch(halo_ctx *ctx, size_t size) {

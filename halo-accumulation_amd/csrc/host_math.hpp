@@ -222,6 +222,7 @@ struct Point {  // Jacobian, Z = 0 infinity
     }
     Affine to_affine() const {
         if (is_inf()) return Affine{Fq::zero(), Fq::zero(), true};
+        if (Z == Fq::one()) return Affine{X, Y, false};  // already normalised (everything the library emits)
         Fq zi = Z.inv(), zi2 = zi.sqr();
         return Affine{X * zi2, Y * zi2 * zi, false};
     }
@@ -232,6 +233,34 @@ struct Point {  // Jacobian, Z = 0 infinity
     }
     void store(u64 *w) const { X.store(w); Y.store(w + 4); Z.store(w + 8); }
     void store_normalized(u64 *w) const { normalized().store(w); }
+};
+
+// k * P for a point used many times (H' of one pcdl::open): 64 windows x 15 multiples, no doublings
+class FixedBaseTable {
+   public:
+    FixedBaseTable() = default;
+    explicit FixedBaseTable(const Point &p) : base_(p), tbl_(64 * 16) {
+        Point w = p;
+        for (int i = 0; i < 64; ++i) {
+            tbl_[16 * i] = Point::infinity();
+            for (int d = 1; d < 16; ++d) tbl_[16 * i + d] = tbl_[16 * i + d - 1] + w;
+            w = tbl_[16 * i + 15] + w;  // 16^(i+1) * P
+        }
+    }
+    bool matches(const Point &p) const { return !tbl_.empty() && base_.X == p.X && base_.Y == p.Y && base_.Z == p.Z; }
+    Point mul(const Fr &k_mont) const {
+        Fr k = k_mont.from_mont();
+        Point acc = Point::infinity();
+        for (int i = 0; i < 64; ++i) {
+            unsigned nib = (unsigned)(k.l[i / 16] >> (4 * (i % 16))) & 15u;
+            if (nib) acc = acc + tbl_[16 * i + nib];
+        }
+        return acc;
+    }
+
+   private:
+    Point base_;
+    std::vector<Point> tbl_;
 };
 
 // sum_i k_i * P_i for a handful of points (succinct check, acc.rs:178): interleaved 4-bit windows

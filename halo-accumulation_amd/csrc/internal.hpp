@@ -73,6 +73,16 @@ struct MsmWorkspace {
     size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0;
     MsmPlan plan{};          // plan of the MSM in flight on this slot
     bool in_flight = false;
+    // hipGraph of the launch sequence, replayed while the same (bases, scalars, n, form, window) repeats
+    struct GraphKey {
+        const void *bases = nullptr, *scalars = nullptr;
+        size_t n = 0;
+        int mont = 0, c = 0;
+        bool operator==(const GraphKey &o) const { return bases == o.bases && scalars == o.scalars && n == o.n && mont == o.mont && c == o.c; }
+    };
+    GraphKey seen_key, graph_key;
+    hipGraphExec_t graph_exec = nullptr;
+    MsmPlan graph_plan{};
 };
 
 }  // namespace halo
@@ -88,6 +98,7 @@ struct halo_ctx {
     halo::MsmWorkspace wss[4];         // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
+    bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -103,6 +114,7 @@ struct halo_ipa {
     uint32_t *d_G = nullptr;  // m x 20 words native affine (in-place)
     uint64_t *d_c = nullptr;  // m x 4
     uint64_t *d_z = nullptr;  // m x 4
+    halo::host::FixedBaseTable hp_table;  // window table of the H' this open uses (pcdl.rs:181)
     hipEvent_t ev = nullptr;  // orders slot 1's stream after the folds queued on stream 0
     // no-fold mode (ipa.hip): G stays at M points, s holds the challenge products
     bool nofold = false;

@@ -649,6 +649,7 @@ void msm_workspace_free(halo_ctx *ctx) {
         for (auto p : p64) (void)hipFree(p);
         for (auto p : p32) (void)hipFree(p);
         if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
+        if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
         ws = MsmWorkspace();
     }
 }
@@ -659,6 +660,8 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
     if (rc) return rc;
     return msm_finish(ctx, 0, out);
 }
+
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n);
 
 struct StreamGuard {  // the launch macro uses ctx->stream
     halo_ctx *ctx;
@@ -678,6 +681,43 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
     ws.plan = MsmPlan{0, 0, 0};
     if (n == 0) { ws.in_flight = true; return HALO_OK; }
     StreamGuard guard(ctx, ctx->streams[slot]);
+    // The launch sequence below is fixed for a given (bases, scalars, n, form, window): the second
+    // time the same key arrives it is captured into a hipGraph, afterwards one graph launch replaces
+    // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
+    // rank's share of a sharded MSM).  Event profiling needs the individual launches.
+    MsmWorkspace::GraphKey key;
+    key.bases = d_bases; key.scalars = d_scalars; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits;
+    bool graphs = ctx->use_graphs && !ctx->prof.on;
+    if (graphs && ws.graph_exec && key == ws.graph_key) {
+        HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
+        ws.plan = ws.graph_plan;
+        ws.in_flight = true;
+        return HALO_OK;
+    }
+    bool capture = graphs && key == ws.seen_key;
+    ws.seen_key = key;
+    if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
+    int rc = msm_enqueue_launches(ctx, ws, d_bases, d_scalars, mont, n);
+    if (capture) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(ctx->streams[slot], &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+        if (ws.graph_exec) { (void)hipGraphExecDestroy(ws.graph_exec); ws.graph_exec = nullptr; }
+        e = hipGraphInstantiate(&ws.graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { ws.graph_exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
+        ws.graph_key = key;
+        ws.graph_plan = ws.plan;
+        HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
+    }
+    if (rc) return rc;
+    ws.in_flight = true;
+    return HALO_OK;
+}
+
+// the launch sequence proper (recorded into a graph when the stream is capturing); sets ws.plan
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
     MsmPlan p = msm_plan(n, ctx->window_bits);
     size_t total = (size_t)p.W * p.B;
@@ -736,7 +776,6 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)p.W * 96, hipMemcpyDeviceToHost, s));
     ws.plan = p;
-    ws.in_flight = true;
     return HALO_OK;
 }
 
