@@ -18,6 +18,8 @@
 //                     core and a > 1 ms serial chain for one GPU lane)
 // msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
 // overlap on the context's slots (workspace + stream each).
+#include <thread>
+
 #include "curve.cuh"
 #include "internal.hpp"
 
@@ -577,10 +579,27 @@ static const std::vector<uint64_t> &urs_table() {
 int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
     const std::vector<uint64_t> &tbl = urs_table();
+    // main.rs:18-32 on the host: n independent SHA3-256 hashes, spread over the host's cores
     std::vector<uint64_t> canon(4 * n);
-    for (size_t i = 0; i < n; ++i) {
-        host::Fr s = host::urs_scalar(first_index + (uint64_t)i * stride).from_mont();
-        s.store(&canon[4 * i]);
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nthreads = hw ? hw : 4;
+        if (nthreads > 32) nthreads = 32;
+        if (nthreads > n / 4096 + 1) nthreads = n / 4096 + 1;
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                host::Fr s = host::urs_scalar(first_index + (uint64_t)i * stride).from_mont();
+                s.store(&canon[4 * i]);
+            }
+        };
+        std::vector<std::thread> th;
+        size_t per = (n + nthreads - 1) / nthreads;
+        for (size_t t = 1; t < nthreads; ++t) {
+            size_t lo = t * per, hi = lo + per < n ? lo + per : n;
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        work(0, per < n ? per : n);
+        for (auto &t : th) t.join();
     }
     uint64_t *d_tbl = nullptr, *d_canon = nullptr;
     uint32_t *d_tbl_native = nullptr;
