@@ -41,12 +41,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HALO_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("HALO_BENCH_BACKEND", "nccl")
+    gpu = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     import halo_accumulation_amd as h
     from halo_accumulation_amd import pcdl
@@ -55,7 +62,7 @@ def main():
     n = 1 << args.log_n
     lo, hi = shard_range(n, rank, world)
     # this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
-    ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=local_rank)
+    ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=gpu)
     # scalars: SplitMix64 seed ...02, generated on the device by the library's
     # own generator; this rank's block starts 4*lo draws into the stream
     GAMMA, MASK = 0x9E3779B97F4A7C15, (1 << 64) - 1
@@ -65,7 +72,7 @@ def main():
     # low-occupancy tail (bucket reduce, D2H of the window sums, host Horner) runs, MSM k+1's
     # recode/sort/accumulate kernels already occupy the CUs.  Every MSM is completed (and, for
     # N > 1, all-gathered and combined) inside the timed region.
-    gather = ShardedMsm(lambda slot: ctx.msm_dev_end(slot), h._lib.point_sum, device=dev)
+    gather = ShardedMsm(lambda slot: ctx.msm_dev_end(slot), h._lib.point_sum, device=coll_dev)
 
     cfg = {"depth": args.depth}
 
@@ -100,7 +107,7 @@ def main():
     out = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -192,6 +199,16 @@ def main():
             result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False,
                                           "algorithmic_bytes": 480 * n, "hbm_roofline_frac": (480 * n / odt) / (HBM_PEAK_GBS * 1e9),
                                           "k_fold_points_ms_per_open": fold_ms}
+    if world > 1 and rank == 0:
+        # cross-check of the sharded result: the same MSM, unsharded, on this rank's GPU alone
+        full = h._lib.Context(urs_n=n, first_index=2, device=gpu)
+        d_all = torch.empty(n * 4, dtype=torch.int64, device=dev)
+        full.rng_scalars_dev(0x48414C4F00000002, n, d_all.data_ptr())
+        result["sharded_equals_single_gpu"] = full.msm_dev(d_all.data_ptr(), n).tolist() == out.tolist()
+        full.close()
+        assert result["sharded_equals_single_gpu"], "sharded MSM differs from the single-GPU MSM"
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
