@@ -115,7 +115,8 @@ HALO_DEV void xyzz_madd(XyzzN &acc, const AffN &q) {
     Fq<2> PPP = fq_mul(Pd, PP);
     Fq<2> Qv = fq_mul(acc.x, PP);
     Fq<8> x3 = fq_sub_sub2(fq_sqr(Rd), PPP, Qv);
-    Fq<4> y3 = fq_sub<2>(fq_mul(Rd, fq_sub<8>(Qv, x3)), fq_mul(acc.y, PPP));
+    // y3 = R (Q - x3) - Y1 PPP as ONE reduction: R (Q - x3) + (8p - Y1) PPP
+    Fq<2> y3 = fq_mul_add_mul(Rd, fq_sub<8>(Qv, x3), fq_neg<8>(acc.y), PPP);
     acc.x = x3;
     acc.y = fq_widen<8>(y3);
     acc.zz = fq_mul(acc.zz, PP);
@@ -140,7 +141,7 @@ HALO_DEV void xyzz_add(XyzzN &acc, const XyzzN &q) {
     Fq<2> PPP = fq_mul(Pd, PP);
     Fq<2> Qv = fq_mul(U1, PP);
     Fq<8> x3 = fq_sub_sub2(fq_sqr(Rd), PPP, Qv);
-    Fq<4> y3 = fq_sub<2>(fq_mul(Rd, fq_sub<8>(Qv, x3)), fq_mul(S1, PPP));
+    Fq<2> y3 = fq_mul_add_mul(Rd, fq_sub<8>(Qv, x3), fq_neg<2>(S1), PPP);
     acc.x = x3;
     acc.y = fq_widen<8>(y3);
     acc.zz = fq_mul(fq_mul(acc.zz, q.zz), PP);
@@ -215,7 +216,7 @@ HALO_DEV JacN jac_madd(const JacN &p, const AffN &q) {
     Fq<2> x3 = fq_tighten(fq_sub_sub2(fq_muls<4>(fq_sqr(r0)), J, V));
     JacN r;
     r.x = fq_widen<8>(x3);
-    r.y = fq_muls<2>(fq_sub<2>(fq_mul(r0, fq_sub<2>(V, x3)), fq_mul(p.y, J)));
+    r.y = fq_widen<8>(fq_muls<2>(fq_mul_add_mul(r0, fq_sub<2>(V, x3), fq_neg<8>(p.y), J)));  // 2 (r0 (V - x3) - Y1 J), one reduction
     r.z = fq_muls<2>(fq_mul(p.z, H));
     return r;
 }

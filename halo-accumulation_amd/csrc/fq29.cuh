@@ -200,6 +200,54 @@ HALO_DEV Fq<2> fq_sqr(const Fq<Ka> &a) {
     return r;
 }
 
+// a*b + c*d with ONE Montgomery reduction: both products accumulate into the same 64-bit columns
+// (18 partial products of < 2^58 still fit) before the nine reduction steps.  Differences of
+// products are formed by passing a negated (K*p - x) operand.
+template <int Ka, int Kb, int Kc, int Kd>
+HALO_DEV Fq<2> fq_mul_add_mul(const Fq<Ka> &a, const Fq<Kb> &b, const Fq<Kc> &c2, const Fq<Kd> &d) {
+    static_assert(Ka * Kb + Kc * Kd <= 120, "fused product bound: (KaKb + KcKd)/128 + 1 must stay < 2");
+    uint64_t c[18];
+    uint64_t k29 = M29;
+    asm volatile("" : "+v"(k29));
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc = k < 9 ? k29 : 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j >= 0 && j < 9) {
+                acc = (uint64_t)a.v[i] * b.v[j] + acc;
+                acc = (uint64_t)c2.v[i] * d.v[j] + acc;
+            }
+        }
+        c[k] = acc;
+    }
+    c[17] = 0;
+    uint32_t p8 = P29::L[8];
+    asm volatile("" : "+v"(p8));
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint64_t t = c[i] + carry;
+        uint32_t m = (~(uint32_t)t) & M29;
+        c[i + 1] = (uint64_t)m * P29::L[1] + c[i + 1];
+        c[i + 2] = (uint64_t)m * P29::L[2] + c[i + 2];
+        c[i + 3] = (uint64_t)m * P29::L[3] + c[i + 3];
+        c[i + 4] = (uint64_t)m * P29::L[4] + c[i + 4];
+        c[i + 8] = (uint64_t)m * p8 + c[i + 8];
+        carry = t >> 29;
+    }
+    c[9] += carry;
+    Fq<2> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i] = (uint32_t)c[9 + i] & M29;
+        c[10 + i] += c[9 + i] >> 29;
+    }
+    r.v[8] = (uint32_t)c[17];
+    return r;
+}
+
 // ------------------------------------------------------------------ linear operations (one carry pass each)
 template <int Ka, int Kb>
 HALO_DEV Fq<Ka + Kb> fq_add(const Fq<Ka> &a, const Fq<Kb> &b) {
