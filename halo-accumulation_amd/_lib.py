@@ -110,6 +110,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HaloError("libhalo_hip.so is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.  If this library pulled in the
+        # system copy first, torch would later load a second runtime and find no device ("No HIP GPUs are
+        # available").  Importing torch first makes both resolve to the copy torch loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)

@@ -1,0 +1,43 @@
+"""bench.py contract: one JSON line with the driver's keys plus the roofline and cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_emits_contract_json():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--steps", "6", "--warmup", "1",
+                          "--cpu-msms", "1", "--open-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly ONE line on stdout"
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 1 and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0
+    assert r["bit_exact_vs_cpu"] is True
+    assert r["pcdl_open_check"]["value"] > 0
+
+
+def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head, _, tail = src.partition("if args.cpu_msms > 0:")
+    assert "import orc" not in head and "orc." not in head, "only the cpu_baseline leg may use oracle/"
+    assert "import orc" in tail

@@ -304,3 +304,30 @@ def test_device_rng_matches_stream(ctx16k):
     st = ctx16k.rng_scalars_dev(0x48414C4F00000002, n, d.data_ptr())
     want, st_ref = orc.rng_scalars(0x48414C4F00000002, n)
     assert d.cpu().numpy().view(np.uint64).reshape(n, 4).tolist() == want.tolist() and st == st_ref
+
+
+def test_api_misuse_is_reported_not_crashed(hal, ctx16k):
+    """Bad sizes / slots / states come back as HaloError with a message; nothing is dereferenced."""
+    import torch
+    n = 16384
+    sc = np.zeros((n + 1, 4), dtype=np.uint64)
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm(sc)                                  # more scalars than bases
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm(sc[:8], off=n - 4)                   # range past the key
+    d = torch.zeros(64 * 4, dtype=torch.int64, device="cuda")
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm_dev_begin(7, d.data_ptr(), 64)       # slot out of range
+    ctx16k.msm_dev_begin(1, d.data_ptr(), 64)
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm_dev_begin(1, d.data_ptr(), 64)       # slot busy
+    assert canon(ctx16k.msm_dev_end(1)) is None         # all-zero scalars
+    with pytest.raises(hal.HaloError):
+        ctx16k.set_window_bits(3)
+    ipa = hal.Ipa(ctx16k, 4, sc[:4], sc[0])
+    with pytest.raises(hal.HaloError):
+        ipa.finish()                                    # rounds remaining
+    with pytest.raises(AssertionError):
+        hal.Ipa(ctx16k, 6, sc[:4], sc[0])               # not a power of two (pcdl.rs:130)
+    with pytest.raises(AssertionError):
+        hal.Ipa(ctx16k, 1 << 15, sc[:4], sc[0])         # larger than the key (pcdl.rs:132)
