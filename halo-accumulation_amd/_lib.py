@@ -66,6 +66,9 @@ _SIGS = {
     "halo_ipa_dot_cz": (C.c_int, [C.c_void_p, u64p]),
     "halo_ipa_round_lr_partial": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "halo_ipa_finish_z": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "halo_ipa_hiding_partial": (C.c_int, [C.c_void_p, C.c_uint64, C.c_size_t, u64p, C.c_uint64, C.c_uint64, u64p]),
+    "halo_ipa_apply_hiding": (C.c_int, [C.c_void_p, u64p]),
+    "halo_open_hiding_combine": (C.c_int, [u64p, u64p, u64p, u64p, C.c_size_t, u64p, C.POINTER(C.c_uint64), C.c_size_t, u64p, u64p, u64p, u64p]),
     "halo_open_start": (C.c_int, [u64p, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_open_combine": (C.c_int, [u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]),
     "halo_ipa_round_lr": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
@@ -334,6 +337,14 @@ class Ipa:
         check(self.ctx.lib.halo_ipa_round_lr_partial(self.h, ptr(rec[:12]), ptr(rec[12:24]), ptr(rec[24:])))
         return rec
 
+    def hiding_partial(self, rng_state: int, deg: int, z, stride: int, offset: int):
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.ctx.lib.halo_ipa_hiding_partial(self.h, rng_state, deg, ptr(np.ascontiguousarray(z, dtype=np.uint64)), stride, offset, ptr(out)))
+        return out
+
+    def apply_hiding(self, alpha):
+        check(self.ctx.lib.halo_ipa_apply_hiding(self.h, ptr(np.ascontiguousarray(alpha, dtype=np.uint64))))
+
     def finish_z(self):
         U, c, z0 = np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
         check(self.ctx.lib.halo_ipa_finish_z(self.h, ptr(U), ptr(c), ptr(z0)))
@@ -374,6 +385,19 @@ def open_start(Cm, z, v_parts):
     check(load().halo_open_start(ptr(np.ascontiguousarray(Cm, dtype=np.uint64)), ptr(np.ascontiguousarray(z, dtype=np.uint64)), ptr(v_parts),
                                  v_parts.shape[0], ptr(v), ptr(xi), ptr(Hp)))
     return v, xi, Hp
+
+
+def open_hiding_combine(Cm, z, v_parts, cbar_parts, w, rng_state: int, deg: int):
+    """-> C_bar, alpha, w', C', advanced rng state"""
+    v_parts = np.ascontiguousarray(v_parts, dtype=np.uint64).reshape(-1, 4)
+    cbar_parts = np.ascontiguousarray(cbar_parts, dtype=np.uint64).reshape(-1, 12)
+    st = C.c_uint64(rng_state)
+    Cbar, alpha, wp, Cp = (np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64),
+                           np.zeros(12, dtype=np.uint64))
+    check(load().halo_open_hiding_combine(ptr(np.ascontiguousarray(Cm, dtype=np.uint64)), ptr(np.ascontiguousarray(z, dtype=np.uint64)),
+                                          ptr(v_parts), ptr(cbar_parts), v_parts.shape[0], ptr(np.ascontiguousarray(w, dtype=np.uint64)),
+                                          C.byref(st), deg, ptr(Cbar), ptr(alpha), ptr(wp), ptr(Cp)))
+    return Cbar, alpha, wp, Cp, st.value
 
 
 def open_combine(parts, Hp, xi_prev):

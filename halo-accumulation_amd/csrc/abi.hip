@@ -557,6 +557,33 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     return HALO_OK;
 }
 
+// hiding branch, sharded (pcdl.rs:140-150): this shard's slice of p_bar = q (X - z) from the rng stream and
+// its share <p_bar_loc, G_loc> of C_bar (without the w_bar S term)
+int halo_ipa_hiding_partial(halo_ipa *st, uint64_t rng_state, size_t deg, const uint64_t z[4], uint64_t stride, uint64_t offset,
+                            uint64_t Cbar_part[12]) {
+    if (!st || !z || !Cbar_part || stride == 0) { set_error("ipa_hiding_partial: bad argument"); return HALO_E_ARG; }
+    halo_ctx *ctx = st->ctx;
+    HALO_CTX(ctx);
+    if (st->m != st->n) { set_error("ipa_hiding_partial: rounds already started"); return HALO_E_ARG; }
+    if (deg == 0) { set_error("open: hiding needs p.degree() >= 1"); return HALO_E_ASSERT; }
+    if (!st->d_pbar && hipMalloc(&st->d_pbar, st->n * 32) != hipSuccess) { set_error("ipa_hiding_partial: allocation failed"); return HALO_E_DEVICE; }
+    int rc = pbar_stream_dev(ctx, rng_state, deg, host::Fr::load(z), stride, offset, st->n, st->d_pbar);
+    if (rc) return rc;
+    host::Point part;
+    rc = msm_run(ctx, st->d_G, st->d_pbar, true, st->n, &part);
+    if (rc) return rc;
+    part.store_normalized(Cbar_part);
+    return HALO_OK;
+}
+// p' = p + alpha p_bar on this shard (pcdl.rs:156)
+int halo_ipa_apply_hiding(halo_ipa *st, const uint64_t alpha[4]) {
+    if (!st || !alpha || !st->d_pbar) { set_error("ipa_apply_hiding: no p_bar on this state"); return HALO_E_ARG; }
+    halo_ctx *ctx = st->ctx;
+    HALO_CTX(ctx);
+    if (st->m != st->n) { set_error("ipa_apply_hiding: rounds already started"); return HALO_E_ARG; }
+    return axpy_dev(ctx, st->d_c, st->d_pbar, st->n, host::Fr::load(alpha));
+}
+
 int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4]) {
     int rc = halo_ipa_finish(st, U, c);
     if (rc) return rc;
@@ -575,6 +602,7 @@ void halo_ipa_destroy(halo_ipa *st) {
     (void)hipFree(st->d_c);
     (void)hipFree(st->d_z);
     (void)hipFree(st->d_s); (void)hipFree(st->d_s2); (void)hipFree(st->d_FL); (void)hipFree(st->d_FR);
+    (void)hipFree(st->d_pbar);
     if (st->ev) (void)hipEventDestroy(st->ev);
     delete st;
 }
@@ -618,6 +646,39 @@ int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v
     host::Point::load(H).mul(x0).store_normalized(Hp_out);  // pcdl.rs:181
     v.store(v_out);
     x0.store(xi0);
+    return HALO_OK;
+}
+// hiding branch, host step (pcdl.rs:147-162): w_bar is the next scalar of the stream after the deg
+// coefficients of q; C_bar = sum of the shards' parts + w_bar S; alpha = rho_0(C, z, v, C_bar);
+// w' = w_bar alpha + w; C' = C + alpha C_bar - w' S.  *rng_state advances past q and w_bar.
+int halo_open_hiding_combine(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, const uint64_t *Cbar_parts, size_t P,
+                             const uint64_t w[4], uint64_t *rng_state, size_t deg, uint64_t Cbar[12], uint64_t alpha[4],
+                             uint64_t w_prime[4], uint64_t C_prime[12]) {
+    if (!C || !z || !v_parts || !Cbar_parts || !w || !rng_state || !Cbar || !alpha || !w_prime || !C_prime || P == 0) {
+        set_error("open_hiding_combine: bad argument");
+        return HALO_E_ARG;
+    }
+    host::Fr v = host::Fr::zero();
+    host::Point Cb = host::Point::infinity();
+    for (size_t i = 0; i < P; ++i) {
+        v = v + host::Fr::load(v_parts + 4 * i);
+        Cb = Cb + host::Point::load(Cbar_parts + 12 * i);
+    }
+    host::Rng rng{*rng_state + 4 * (uint64_t)deg * 0x9E3779B97F4A7C15ULL};  // past the deg coefficients of q (pcdl.rs:141)
+    host::Fr w_bar = rng.scalar();                                          // pcdl.rs:147
+    *rng_state = rng.state;
+    uint64_t Sw[12], Hw[12];
+    halo_public_points(Sw, Hw);
+    host::Point S = host::Point::load(Sw), Cp = host::Point::load(C);
+    Cb = (S.mul(w_bar) + Cb).normalized();                                  // pcdl.rs:150 via pedersen.rs:15-17
+    host::Transcript t;
+    t.point(Cp); t.scalar(host::Fr::load(z)); t.scalar(v); t.point(Cb);
+    host::Fr a = t.finish(0);                                               // pcdl.rs:153
+    host::Fr wp = w_bar * a + host::Fr::load(w);                            // pcdl.rs:159
+    (Cp + Cb.mul(a) - S.mul(wp)).store_normalized(C_prime);                 // pcdl.rs:162
+    Cb.store(Cbar);
+    a.store(alpha);
+    wp.store(w_prime);
     return HALO_OK;
 }
 // parts: P records of L 12 | R 12 | dot_l 4 | dot_r 4 in rank order

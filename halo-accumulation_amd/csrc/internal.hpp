@@ -120,6 +120,7 @@ struct halo_ipa {
     bool nofold = false;
     size_t M = 0, s_len = 0;
     uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
+    uint64_t *d_pbar = nullptr;  // n x 4: this shard of p_bar (hiding branch of the sharded open)
 };
 
 namespace halo {
@@ -157,6 +158,8 @@ int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, co
 int rng_scalars_dev(halo_ctx *ctx, uint64_t state0, size_t n, uint64_t *d_out);
 int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, uint64_t *d_out);
 int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a);
+int pbar_stream_dev(halo_ctx *ctx, uint64_t state0, size_t deg, const host::Fr &z, uint64_t stride, uint64_t offset, size_t n_local,
+                    uint64_t *d_out);
 int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_L, uint64_t *d_R);
 int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out);
 

@@ -231,13 +231,12 @@ HALO_DEV uint64_t splitmix_at(uint64_t s0, uint64_t k) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-__global__ __launch_bounds__(256) void k_rng_scalars(uint64_t s0, uint32_t n, uint64_t *__restrict__ out) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// element `idx` of the scalar stream that starts after state s0, in Montgomery form
+HALO_DEV Fe rng_scalar_at(uint64_t s0, uint64_t idx) {
     Fe v;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint64_t w = splitmix_at(s0, 4 * (uint64_t)i + k + 1);
+        uint64_t w = splitmix_at(s0, 4 * idx + k + 1);
         v.v[2 * k] = (uint32_t)w;
         v.v[2 * k + 1] = (uint32_t)(w >> 32);
     }
@@ -257,7 +256,27 @@ __global__ __launch_bounds__(256) void k_rng_scalars(uint64_t s0, uint32_t n, ui
             for (int k = 0; k < 8; k++) v.v[k] = d[k];
         }
     }
-    fe_store(out + 4 * (size_t)i, fe_to_mont<FrCfg>(v));
+    return fe_to_mont<FrCfg>(v);
+}
+__global__ __launch_bounds__(256) void k_rng_scalars(uint64_t s0, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    fe_store(out + 4 * (size_t)i, rng_scalar_at(s0, i));
+}
+// A cyclic shard of p_bar = q (X - z) straight from the stream (q is never materialised):
+// out[j] = p_bar[offset + j*stride] = q[i-1] - z q[i], q[k] = stream element k for k < deg, else 0
+__global__ __launch_bounds__(256) void k_pbar_stream(uint64_t s0, uint32_t deg, FeArg zarg, uint32_t stride, uint32_t offset,
+                                                     uint32_t n_local, uint64_t *__restrict__ out) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_local) return;
+    uint64_t i = (uint64_t)offset + (uint64_t)j * stride;
+    Fe r = fe_zero();
+    if (i <= deg) {
+        Fe lo = (i >= 1) ? rng_scalar_at(s0, i - 1) : fe_zero();
+        Fe hi = (i < deg) ? rng_scalar_at(s0, i) : fe_zero();
+        r = fe_sub<FrCfg>(lo, fe_mul<FrCfg>(from_arg(zarg), hi));
+    }
+    fe_store(out + 4 * (size_t)j, r);
 }
 // p_bar = q * (X - z): p_bar[i] = q[i-1] - z q[i], i in [0, deg]; q has deg coefficients (pcdl.rs:140-142)
 __global__ __launch_bounds__(256) void k_pbar(const uint64_t *__restrict__ q, uint32_t deg, FeArg zarg, uint64_t *__restrict__ out) {
@@ -473,6 +492,15 @@ int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const hos
 int fr_scale(halo_ctx *ctx, uint64_t *d_v, size_t n, const host::Fr &a) {
     if (n == 0) return HALO_OK;
     HALO_LAUNCH(ctx, "k_scale", k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_v, (uint32_t)n, to_arg(a));
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int pbar_stream_dev(halo_ctx *ctx, uint64_t state0, size_t deg, const host::Fr &z, uint64_t stride, uint64_t offset, size_t n_local,
+                    uint64_t *d_out) {
+    if (n_local == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_pbar_stream", k_pbar_stream, dim3((unsigned)((n_local + 255) / 256)), dim3(256), 0, state0, (uint32_t)deg, to_arg(z),
+                (uint32_t)stride, (uint32_t)offset, (uint32_t)n_local, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

@@ -99,13 +99,25 @@ class ShardedOpen:
             ipa.round_fold(xi, xi_inv)
         return xi
 
-    def open(self, coeffs_local, Cm, z):
-        """coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).  -> (proof, v)"""
+    def open(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
+        """coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).
+        Hiding (pcdl.rs:137-164): pass the commitment randomness w, rng = [SplitMix64 state] (mutated, the
+        same on every rank) and deg = p.degree().  -> (proof, v)"""
         P, nl = self.world, self.n // self.world
         lg_n = self.n.bit_length() - 1
         ipa = self.lib.Ipa(self.ctx, nl, coeffs_local, z, stride=P, offset=self.rank)
         v_part = ipa.dot_cz()  # this shard's share of p(z)
-        v_parts = self.allgather(v_part) if P > 1 else v_part[None]
+        hiding = w is not None
+        Cbar = wp = None
+        if hiding:
+            cb_part = ipa.hiding_partial(rng[0], deg, z, P, self.rank)  # slice of p_bar from the stream + its MSM
+            rec = self.allgather(np.concatenate([v_part, cb_part])) if P > 1 else np.concatenate([v_part, cb_part])[None]
+            v_parts = np.ascontiguousarray(rec[:, :4])
+            Cbar, alpha, wp, C_prime, rng[0] = self.lib.open_hiding_combine(Cm, z, v_parts, np.ascontiguousarray(rec[:, 4:]), w, rng[0], deg)
+            ipa.apply_hiding(alpha)  # p' = p + alpha p_bar
+            Cm = C_prime
+        else:
+            v_parts = self.allgather(v_part) if P > 1 else v_part[None]
         v, xi, Hp = self.lib.open_start(Cm, z, v_parts)
         Ls, Rs = [], []
         xi = self._rounds(ipa, nl.bit_length() - 1, Hp, xi, Ls, Rs, P)
@@ -131,6 +143,11 @@ class ShardedOpen:
         o = 2 + 24 * lg_n
         proof[o: o + 12] = U
         proof[o + 12: o + 16] = c
-        proof[o + 16: o + 20] = _FQ_ONE  # C_bar = None: the point at infinity
-        proof[o + 20: o + 24] = _FQ_ONE
+        if hiding:
+            proof[0] = 1
+            proof[o + 16: o + 28] = Cbar
+            proof[o + 28: o + 32] = wp
+        else:
+            proof[o + 16: o + 20] = _FQ_ONE  # C_bar = None: the point at infinity
+            proof[o + 20: o + 24] = _FQ_ONE
         return proof, v

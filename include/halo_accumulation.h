@@ -107,6 +107,16 @@ int halo_ipa_begin_vectors(halo_ctx *ctx, size_t n, const uint64_t *c_vec, const
 int halo_ipa_dot_cz(halo_ipa *st, uint64_t out[4]);
 /* this shard's <c_r, G_l>, <c_l, G_r> (no H' term) and dots = <c_r, z_l> | <c_l, z_r> */
 int halo_ipa_round_lr_partial(halo_ipa *st, uint64_t L[12], uint64_t R[12], uint64_t dots[8]);
+/* hiding branch (pcdl.rs:137-164): this shard's slice of p_bar = q (X - z), q = `deg` scalars of the stream
+ * after rng_state, and its share of <p_bar, G> */
+int halo_ipa_hiding_partial(halo_ipa *st, uint64_t rng_state, size_t deg, const uint64_t z[4], uint64_t stride, uint64_t offset,
+                            uint64_t Cbar_part[12]);
+/* c <- c + alpha p_bar on this shard */
+int halo_ipa_apply_hiding(halo_ipa *st, const uint64_t alpha[4]);
+/* host step of the hiding branch: C_bar, alpha, w', C' from the gathered parts; advances *rng_state past q and w_bar */
+int halo_open_hiding_combine(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, const uint64_t *Cbar_parts, size_t P,
+                             const uint64_t w[4], uint64_t *rng_state, size_t deg, uint64_t Cbar[12], uint64_t alpha[4],
+                             uint64_t w_prime[4], uint64_t C_prime[12]);
 /* halo_ipa_finish plus z[0] */
 int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4]);
 /* host steps between collectives: v = sum of the shards' <c, z>, xi_0 = rho_0(C, z, v), H' = xi_0 H (pcdl.rs:135,180-181) */

@@ -301,22 +301,27 @@ def _sharded_worker(rank, world, port, n, q):
     full = np.zeros((n, 4), dtype=np.uint64); full[: n - 3] = coeffs
     so = ShardedOpen(h._lib, rank, world, allgather)
     so.load_key(n)
-    if rank == 0:
-        ref = h._lib.Context(urs_n=n)
-        C = pcdl.commit(ref, coeffs, n - 1)
-        want = pcdl.open(ref, [1], coeffs, C, n - 1, z[0])
-        Cs = torch.from_numpy(C.view(np.int64).copy())
-    else:
-        Cs = torch.zeros(12, dtype=torch.int64)
-    dist.broadcast(Cs, 0)
-    C = Cs.numpy().view(np.uint64)
-    proof, v = so.open(np.ascontiguousarray(full[rank::world]), C, z[0])
-    ok = True
-    if rank == 0:
-        ok = proof.tolist() == want.tolist()
-        pcdl.check_proof(ref, C, n - 1, z[0], v, proof)
-        ref.close()
-    q.put((rank, ok, proof.tolist()))
+    wz, _ = orc.rng_scalars(s + 99, 1)
+    ok, proofs = True, []
+    for w in (None, wz[0]):  # non-hiding, then hiding (pcdl.rs:137-164)
+        if rank == 0:
+            ref = h._lib.Context(urs_n=n)
+            C = pcdl.commit(ref, coeffs, n - 1, w)
+            rng_ref = [4242]
+            want = pcdl.open(ref, rng_ref, coeffs, C, n - 1, z[0], w)
+            Cs = torch.from_numpy(C.view(np.int64).copy())
+        else:
+            Cs = torch.zeros(12, dtype=torch.int64)
+        dist.broadcast(Cs, 0)
+        C = Cs.numpy().view(np.uint64)
+        rng = [4242]
+        proof, v = so.open(np.ascontiguousarray(full[rank::world]), C, z[0], w=w, rng=rng, deg=n - 4)
+        if rank == 0:
+            ok = ok and proof.tolist() == want.tolist() and rng[0] == rng_ref[0]
+            pcdl.check_proof(ref, C, n - 1, z[0], v, proof)
+            ref.close()
+        proofs.append(proof.tolist())
+    q.put((rank, ok, proofs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -353,3 +358,9 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     proof, v = so.open(coeffs, C, z[0])
     assert proof.tolist() == pcdl.open(ctx, [1], coeffs, C, n - 1, z[0]).tolist()
     assert v.tolist() == ctx.poly_eval(coeffs, z[0]).tolist()
+    # hiding branch: same proof and same final rng state as pcdl::open
+    w, _ = orc.rng_scalars(5, 1)
+    Ch = pcdl.commit(ctx, coeffs, n - 1, w[0])
+    r1, r2 = [77], [77]
+    proof, _ = so.open(coeffs, Ch, z[0], w=w[0], rng=r1, deg=n - 1)
+    assert proof.tolist() == pcdl.open(ctx, r2, coeffs, Ch, n - 1, z[0], w[0]).tolist() and r1 == r2
