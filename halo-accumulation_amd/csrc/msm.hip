@@ -282,10 +282,16 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     if (cnt > kmax) cnt = kmax;
     uint32_t st = scan_at(starts, blockoff, g) + first;
     XyzzN acc = xyzz_inf();
+    // the next point's index and coordinates are fetched before the current mixed add is issued, so the
+    // gather latency hides behind ~10k cycles of arithmetic even at two waves per SIMD
+    uint32_t e = sorted[st];
+    AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
     for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t e = sorted[st + k];
-        AffN p = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
-        p = aff_cneg(p, (e >> 31) != 0);
+        AffN p = aff_cneg(nxt, (e >> 31) != 0);
+        if (k + 1 < cnt) {
+            e = sorted[st + k + 1];
+            nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+        }
         xyzz_madd(acc, p);
     }
     xyzz_store(partial + XYZZ_WORDS * (size_t)t, acc);
