@@ -151,7 +151,7 @@ def main():
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
                        "sharding": "block index shard per rank + RCCL all-gather of 96 B partials" if world > 1 else "single GPU",
                        "msms_in_flight": args.depth,
-                       "window_bits": "auto (c = floor(log2 n) - 4, clamped to [4,16])"},
+                       "window_bits": "auto (16 at n >= 2^20; measured table below, msm.hip msm_plan)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_msms_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),

@@ -93,6 +93,7 @@ _SIGS = {
     "halo_prof_count": (C.c_int, [C.c_void_p]),
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -290,6 +291,9 @@ class Context:
 
     def set_window_bits(self, c):
         check(self.lib.halo_set_window_bits(self.h, c))
+
+    def set_reduce_span(self, span):
+        check(self.lib.halo_set_reduce_span(self.h, span))
 
     # ---- primitive hooks
     def field_op(self, field, op, a, b=None):

@@ -746,6 +746,12 @@ int halo_set_window_bits(halo_ctx *ctx, int c) {
     return HALO_OK;
 }
 
+int halo_set_reduce_span(halo_ctx *ctx, int span) {
+    if (!ctx || span < 0 || span > 512 || (span & (span - 1))) { set_error("reduce span must be 0 or a power of two <= 512"); return HALO_E_ARG; }
+    ctx->reduce_span = span;
+    return HALO_OK;
+}
+
 // ------------------------------------------------------------------ primitive hooks
 int halo_test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
     HALO_CTX(ctx);

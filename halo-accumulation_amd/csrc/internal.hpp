@@ -77,8 +77,10 @@ struct MsmWorkspace {
     struct GraphKey {
         const void *bases = nullptr, *scalars = nullptr;
         size_t n = 0;
-        int mont = 0, c = 0;
-        bool operator==(const GraphKey &o) const { return bases == o.bases && scalars == o.scalars && n == o.n && mont == o.mont && c == o.c; }
+        int mont = 0, c = 0, span = 0;
+        bool operator==(const GraphKey &o) const {
+            return bases == o.bases && scalars == o.scalars && n == o.n && mont == o.mont && c == o.c && span == o.span;
+        }
     };
     GraphKey seen_key, graph_key;
     hipGraphExec_t graph_exec = nullptr;
@@ -92,12 +94,13 @@ constexpr int HALO_SLOTS = 4;
 struct halo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
-    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t streams[HALO_SLOTS] = {};
     size_t n = 0;
     uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.cuh AffN)
-    halo::MsmWorkspace wss[4];         // slots (workspace + stream) so that independent MSMs can overlap
+    halo::MsmWorkspace wss[HALO_SLOTS];        // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
+    int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
     // scratch for host-pointer entry points

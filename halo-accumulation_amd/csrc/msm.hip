@@ -29,9 +29,12 @@ namespace halo {
 MsmPlan msm_plan(size_t n, int forced_c) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    // large MSMs are throughput-bound: ~32 points per bucket amortise the bucket reduction;
-    // below 2^18 points the serial chain per bucket dominates, so spread over more buckets
-    int c = forced_c > 0 ? forced_c : (lg >= 18 ? lg - 4 : lg - 2);
+    // Measured on gfx950 (tools/sweep_msm.py, solo latency and 4-deep pipelined throughput agree):
+    // large MSMs are throughput-bound, ~32 points per bucket amortise the bucket reduction; below
+    // 2^19 points the serial chains dominate.  Window sizes whose top window keeps only 2-3 scalar
+    // bits (c = 14, 12, 11, 9) are avoided: that window puts n/4 points into each of ~4 buckets.
+    static const int table[] = {/*lg 10*/ 8, 8, 8, 10, 10, 13, 13, 15, 15, /*lg 19*/ 15};
+    int c = forced_c > 0 ? forced_c : (lg >= 20 ? 16 : lg >= 10 ? table[lg - 10] : lg - 2);
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     MsmPlan p;
@@ -711,7 +714,7 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.scalars = d_scalars; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits;
+    key.bases = d_bases; key.scalars = d_scalars; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span;
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     if (graphs && ws.graph_exec && key == ws.graph_key) {
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
@@ -789,11 +792,19 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
                 ws.d_biglist, ws.d_buckets);
     uint32_t L, nseg;
     int logL = 0;
-    // one bucket per lane while that keeps <= 64 segments per window (shortest serial chain),
-    // more buckets per lane only for the large windows
+    // buckets per lane (L) against segments per window: a lane's 2L serial adds are all useful work,
+    // the ~16 wave-wide scan steps that follow are mostly not, so L grows with the window
     if (p.B <= 64) { nseg = 1; L = 1; }
-    else if (p.B <= 4096) { L = 1; nseg = p.B / 64; }
-    else { L = p.B / 4096; nseg = 64; }
+    else {
+        L = p.B >= 16384 ? 8 : p.B >= 4096 ? 4 : p.B >= 1024 ? 2 : 1;
+        nseg = p.B / (64 * L);
+    }
+    if (ctx->reduce_span > 0 && p.B > 64) {
+        L = (uint32_t)ctx->reduce_span;
+        while (64 * L > p.B) L >>= 1;
+        while (p.B / (64 * L) > 64) L <<= 1;
+        nseg = p.B / (64 * L);
+    }
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);

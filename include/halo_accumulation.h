@@ -187,6 +187,8 @@ int halo_set_graphs(halo_ctx *ctx, int on);
 int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 /* MSM tuning: window bits (0 = automatic) */
 int halo_set_window_bits(halo_ctx *ctx, int c);
+/* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */
+int halo_set_reduce_span(halo_ctx *ctx, int span);
 
 /* ---- primitive hooks used by the parity tests (elementwise over n) ----------------------- */
 /* host-only: GLV split of the fold scalar (host_math.hpp): out = s1[5] | s2[5] | e[3] | neg12 | nbits | 0 */
