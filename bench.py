@@ -5,8 +5,9 @@
 
 A step = one MSM over n random scalars (resident in HBM) and the URS bases G_0..G_{n-1}
 (derived on the GPU by the reference's main.rs rule).  N > 1 (launched by torch.distributed.run,
-one rank per GPU): the SAME n-point MSM is index-sharded, each rank reduces its block to one
-point and the partials are all-gathered over RCCL and summed (strong scaling).
+one rank per GPU): the SAME n-point MSMs are sharded -- by Pippenger windows (default: every rank keeps
+the key and the scalars and does 1/N of the bucket work) or by base/scalar index (--shard index) -- each
+rank reduces its share to one point and the partials are all-gathered over RCCL and summed (strong scaling).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -33,7 +34,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--depth", type=int, default=4, help="independent MSMs in flight (1..4)")
+    ap.add_argument("--depth", type=int, default=4, help="launch sequences in flight (1..4)")
+    ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one GPU, 4 on several)")
+    ap.add_argument("--shard", choices=["window", "index"], default="window",
+                    help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index")
     ap.add_argument("--open-steps", type=int, default=2, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     args = ap.parse_args()
@@ -60,53 +64,71 @@ def main():
     from halo_accumulation_amd.sharded import ShardedMsm, shard_range
 
     n = 1 << args.log_n
-    lo, hi = shard_range(n, rank, world)
-    # this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
+    batch = args.batch if args.batch > 0 else (1 if world == 1 else 4)
+    window_mode = world > 1 and args.shard == "window"
+    if window_mode:
+        # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes
+        # the Pippenger windows [r*W/P, (r+1)*W/P) of every MSM: 1/P of the bucket work at full-size efficiency
+        lo, hi, part, parts = 0, n, rank, world
+    else:
+        # index shard: this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
+        (lo, hi), part, parts = shard_range(n, rank, world), 0, 1
     ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=gpu)
-    # scalars: SplitMix64 seed ...02, generated on the device by the library's
-    # own generator; this rank's block starts 4*lo draws into the stream
-    GAMMA, MASK = 0x9E3779B97F4A7C15, (1 << 64) - 1
-    d_sc = torch.empty((hi - lo) * 4, dtype=torch.int64, device=dev)
-    ctx.rng_scalars_dev((0x48414C4F00000002 + 4 * lo * GAMMA) & MASK, hi - lo, d_sc.data_ptr())
-    # Independent MSMs are pipelined over the context's two workspaces/streams: while MSM k's
-    # low-occupancy tail (bucket reduce, D2H of the window sums, host Horner) runs, MSM k+1's
-    # recode/sort/accumulate kernels already occupy the CUs.  Every MSM is completed (and, for
-    # N > 1, all-gathered and combined) inside the timed region.
-    gather = ShardedMsm(lambda slot: ctx.msm_dev_end(slot), h._lib.point_sum, device=coll_dev)
+    # scalars: SplitMix64 seed ...02, generated on the device by the library's own
+    # generator.  MSM j of a launch takes the j-th block of n scalars of that stream (4 draws per scalar).
+    GAMMA, MASK, SEED = 0x9E3779B97F4A7C15, (1 << 64) - 1, 0x48414C4F00000002
+    d_sets = []
+    for j in range(batch):
+        d = torch.empty((hi - lo) * 4, dtype=torch.int64, device=dev)
+        ctx.rng_scalars_dev((SEED + 4 * (j * n + lo) * GAMMA) & MASK, hi - lo, d.data_ptr())
+        d_sets.append(d)
+    ptrs = [d.data_ptr() for d in d_sets]
+    # Independent MSMs are pipelined: `batch` of them share one launch sequence (their windows run side by
+    # side through every kernel) and up to `depth` launches are in flight on the context's slots, so that
+    # one launch's low-occupancy tail (bucket reduce, D2H of the window sums, host Horner) overlaps the
+    # next one's sort/accumulate kernels.  Every MSM is completed (and, for N > 1, all-gathered and
+    # combined) inside the timed region.
+    gather = ShardedMsm(None, h._lib.point_sum, device=coll_dev)
 
     cfg = {"depth": args.depth}
+    outs = [None] * batch  # latest combined result per scalar set
 
     def run_steps(k):
-        nonlocal_depth = cfg["depth"]
-        # local partials are combined across ranks in batches of `depth` (one all-gather per batch)
-        out, pending, parts = None, [], []
-        for step in range(k):
-            slot = step % nonlocal_depth
-            if len(pending) == nonlocal_depth:
-                parts.append(ctx.msm_dev_end(pending.pop(0)))
-                if len(parts) == nonlocal_depth:
-                    out = gather.gather_batch(parts)[-1]
-                    parts = []
-            ctx.msm_dev_begin(slot, d_sc.data_ptr(), hi - lo)
-            pending.append(slot)
+        depth = cfg["depth"]
+        pending = []  # (slot, members)
+
+        def finish():
+            slot, m = pending.pop(0)
+            partials = ctx.msm_dev_batch_end(slot, m)
+            for j, pt in enumerate(gather.gather_batch([partials[j] for j in range(m)])):  # one all-gather per launch
+                outs[j] = pt
+
+        launches = 0
+        while k > 0:
+            m = min(batch, k)
+            if len(pending) == depth:
+                finish()
+            slot = launches % depth
+            ctx.msm_dev_batch_begin(slot, ptrs[:m], hi - lo, part=part, parts=parts)
+            pending.append((slot, m))
+            launches += 1
+            k -= m
         while pending:
-            parts.append(ctx.msm_dev_end(pending.pop(0)))
-        if parts:
-            out = gather.gather_batch(parts)[-1]
-        return out
+            finish()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(3 * args.depth)  # untimed: every slot allocates its workspace and captures its launch graph
-    out = run_steps(args.warmup)
+    run_steps(3 * args.depth * batch)  # untimed: every slot allocates its workspace and captures its launch graph
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    out = run_steps(args.steps)
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    out = outs[0]
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -115,18 +137,19 @@ def main():
     # Kernel durations for the roofline: HIP events on the stream each kernel is launched on, in two
     # extra passes of the same loop right after the timed region (the event brackets need individual
     # launches, the timed region replays the launch sequence as a hipGraph): (a) as timed, several
-    # MSMs in flight -- kernels of different slots time-share the CUs and every duration stretches;
-    # (b) one MSM in flight: the kernel by itself, which is what a roofline fraction is about.
+    # launches in flight -- kernels of different slots time-share the CUs and every duration stretches;
+    # (b) one launch in flight: the kernel by itself, which is what a roofline fraction is about.
+    prof_steps = max(batch, min(args.steps, 8 * batch) // batch * batch)  # whole launches only
     ctx.prof_enable(2)
     ctx.prof_reset()
     barrier()
-    run_steps(min(args.steps, 8))
+    run_steps(prof_steps)
     barrier()
     prof = ctx.prof()
-    cfg["depth"], solo_steps = 1, min(args.steps, 8)
+    cfg["depth"] = 1
     ctx.prof_reset()
     barrier()
-    run_steps(solo_steps)
+    run_steps(prof_steps)
     barrier()
     prof_solo = ctx.prof()
     cfg["depth"] = args.depth
@@ -137,7 +160,9 @@ def main():
         acc_ms, acc_cnt = prof_solo.get("k_msm_accumulate", (0.0, 0))
         kern_s = acc_ms / max(acc_cnt, 1) * 1e-3
         ovl_ms, ovl_cnt = prof.get("k_msm_accumulate", (0.0, 0))
-        alg_bytes = 96 * (hi - lo) + 64  # 64 B base + 32 B scalar per point, one point out
+        # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
+        # index block or their 1/parts window share on this rank)
+        alg_bytes = batch * (96 * (hi - lo) // parts + 64)
         traffic = None  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (n = 2^20, 1 GPU only)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if world == 1 and args.log_n == 20 and os.path.exists(pmc):
@@ -149,12 +174,14 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
-                       "sharding": "block index shard per rank + RCCL all-gather of 96 B partials" if world > 1 else "single GPU",
-                       "msms_in_flight": args.depth,
+                       "sharding": "single GPU" if world == 1 else
+                                   ("Pippenger windows split over the ranks (key + scalars replicated), RCCL all-gather of 96 B partials" if window_mode
+                                    else "block index shard per rank + RCCL all-gather of 96 B partials"),
+                       "msms_per_launch": batch, "launches_in_flight": args.depth,
                        "window_bits": "auto (16 at n >= 2^20; measured table below, msm.hip msm_plan)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_msms_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
+                         "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
                          "algorithmic_bytes": alg_bytes,
                          "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
             "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
@@ -165,7 +192,7 @@ def main():
         gs = ctx.read_bases()
         if args.cpu_msms > 0:
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
-            sc_all = np.ascontiguousarray(d_sc.cpu().numpy().view(np.uint64).reshape(n, 4))
+            sc_all = np.ascontiguousarray(d_sets[0].cpu().numpy().view(np.uint64).reshape(n, 4))
             assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
             t0 = time.perf_counter()
             for _ in range(args.cpu_msms):
@@ -200,13 +227,17 @@ def main():
                                           "algorithmic_bytes": 480 * n, "hbm_roofline_frac": (480 * n / odt) / (HBM_PEAK_GBS * 1e9),
                                           "k_fold_points_ms_per_open": fold_ms}
     if world > 1 and rank == 0:
-        # cross-check of the sharded result: the same MSM, unsharded, on this rank's GPU alone
-        full = h._lib.Context(urs_n=n, first_index=2, device=gpu)
-        d_all = torch.empty(n * 4, dtype=torch.int64, device=dev)
-        full.rng_scalars_dev(0x48414C4F00000002, n, d_all.data_ptr())
-        result["sharded_equals_single_gpu"] = full.msm_dev(d_all.data_ptr(), n).tolist() == out.tolist()
-        full.close()
-        assert result["sharded_equals_single_gpu"], "sharded MSM differs from the single-GPU MSM"
+        # cross-check of the sharded results: the same MSMs, unsharded, on this rank's GPU alone
+        full = ctx if window_mode else h._lib.Context(urs_n=n, first_index=2, device=gpu)
+        ok = True
+        for j in sorted({0, batch - 1}):
+            d_all = torch.empty(n * 4, dtype=torch.int64, device=dev)
+            full.rng_scalars_dev((SEED + 4 * j * n * GAMMA) & MASK, n, d_all.data_ptr())
+            ok = ok and full.msm_dev(d_all.data_ptr(), n).tolist() == outs[j].tolist()
+        result["sharded_equals_single_gpu"] = ok
+        if not window_mode:
+            full.close()
+        assert ok, "sharded MSM differs from the single-GPU MSM"
     if world > 1:
         dist.barrier()
     if rank == 0:

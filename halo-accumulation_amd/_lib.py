@@ -93,7 +93,11 @@ _SIGS = {
     "halo_prof_count": (C.c_int, [C.c_void_p]),
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_msm_dev_begin_part": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "halo_msm_dev_batch_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "halo_msm_dev_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, u64p]),
     "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -198,12 +202,27 @@ class Context:
         check(self.lib.halo_msm_dev(self.h, off, n, C.c_void_p(dptr), int(mont), ptr(out)))
         return out
 
-    def msm_dev_begin(self, slot: int, dptr: int, n: int, off=0, mont=True):
-        check(self.lib.halo_msm_dev_begin(self.h, slot, off, n, C.c_void_p(dptr), int(mont)))
+    def msm_dev_begin(self, slot: int, dptr: int, n: int, off=0, mont=True, part=0, parts=1):
+        """parts > 1: only window shard `part` of `parts` (the partial results of all parts sum to the MSM)"""
+        if parts == 1:
+            check(self.lib.halo_msm_dev_begin(self.h, slot, off, n, C.c_void_p(dptr), int(mont)))
+        else:
+            check(self.lib.halo_msm_dev_begin_part(self.h, slot, off, n, C.c_void_p(dptr), int(mont), part, parts))
 
     def msm_dev_end(self, slot: int):
         out = np.zeros(12, dtype=np.uint64)
         check(self.lib.halo_msm_dev_end(self.h, slot, ptr(out)))
+        return out
+
+    def msm_dev_batch_begin(self, slot: int, dptrs, n: int, off=0, mont=True, part=0, parts=1):
+        """len(dptrs) (1..8) MSMs over the same bases, one resident scalar array each, as one launch sequence;
+        parts > 1: window shard `part` of each"""
+        arr = (C.c_void_p * len(dptrs))(*[C.c_void_p(int(p)) for p in dptrs])
+        check(self.lib.halo_msm_dev_batch_begin(self.h, slot, off, n, arr, len(dptrs), int(mont), part, parts))
+
+    def msm_dev_batch_end(self, slot: int, batch: int):
+        out = np.zeros((batch, 12), dtype=np.uint64)
+        check(self.lib.halo_msm_dev_batch_end(self.h, slot, batch, ptr(out)))
         return out
 
     def msm_points(self, pts_jac, scalars):
@@ -294,6 +313,9 @@ class Context:
 
     def set_reduce_span(self, span):
         check(self.lib.halo_set_reduce_span(self.h, span))
+
+    def set_task_len(self, n):
+        check(self.lib.halo_set_task_len(self.h, n))
 
     # ---- primitive hooks
     def field_op(self, field, op, a, b=None):

@@ -260,6 +260,16 @@ int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void
     if (off + n > ctx->n || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     return msm_enqueue(ctx, slot, ctx->d_bases + 32 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n);
 }
+int halo_msm_dev_begin_part(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int mont, int part, int parts) {
+    HALO_CTX(ctx);
+    if (off + n > ctx->n || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    MsmBatch one;
+    one.count = 1;
+    one.scalars[0] = static_cast<const uint64_t *>(d_scalars);
+    one.part = part;
+    one.parts = parts;
+    return msm_enqueue_batch(ctx, slot, ctx->d_bases + 32 * off, one, mont != 0, n);
+}
 int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
     HALO_CTX(ctx);
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
@@ -267,6 +277,31 @@ int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
     int rc = msm_finish(ctx, slot, &r);
     if (rc) return rc;
     r.store_normalized(out);
+    return HALO_OK;
+}
+
+int halo_msm_dev_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *const *d_scalars, size_t batch, int mont, int part,
+                             int parts) {
+    HALO_CTX(ctx);
+    if (batch < 1 || batch > (size_t)MSM_MAX_BATCH || !d_scalars) { set_error("msm: batch must be in [1, 8]"); return HALO_E_ARG; }
+    if (off + n > ctx->n) { set_error("msm: bad range"); return HALO_E_ARG; }
+    MsmBatch members;
+    members.count = (int)batch;
+    members.part = part;
+    members.parts = parts;
+    for (size_t b = 0; b < batch; ++b) {
+        if (n && !d_scalars[b]) { set_error("msm: null scalar pointer in batch"); return HALO_E_ARG; }
+        members.scalars[b] = static_cast<const uint64_t *>(d_scalars[b]);
+    }
+    return msm_enqueue_batch(ctx, slot, ctx->d_bases + 32 * off, members, mont != 0, n);
+}
+int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out) {
+    HALO_CTX(ctx);
+    if (!out || batch < 1 || batch > (size_t)MSM_MAX_BATCH) { set_error("msm: null output or bad batch"); return HALO_E_ARG; }
+    host::Point r[MSM_MAX_BATCH];
+    int rc = msm_finish_batch(ctx, slot, r, (int)batch);
+    if (rc) return rc;
+    for (size_t b = 0; b < batch; ++b) r[b].store_normalized(out + 12 * b);
     return HALO_OK;
 }
 
@@ -749,6 +784,12 @@ int halo_set_window_bits(halo_ctx *ctx, int c) {
 int halo_set_reduce_span(halo_ctx *ctx, int span) {
     if (!ctx || span < 0 || span > 512 || (span & (span - 1))) { set_error("reduce span must be 0 or a power of two <= 512"); return HALO_E_ARG; }
     ctx->reduce_span = span;
+    return HALO_OK;
+}
+
+int halo_set_task_len(halo_ctx *ctx, int len) {
+    if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }
+    ctx->task_len = len;
     return HALO_OK;
 }
 

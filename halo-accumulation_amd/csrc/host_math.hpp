@@ -83,42 +83,37 @@ struct Fp {
         sub_limbs(r.l, P::M, l);
         return r;
     }
-    // Montgomery product, product scanning with a 192-bit column accumulator
+    // Montgomery product, coarsely integrated operand scanning (CIOS), fully unrolled: t stays below 2M
+    // after every round, so four limbs plus a carry word hold it
     Fp operator*(const Fp &o) const {
-        u64 t[8];
-        u128 acc = 0;
-        u64 hi = 0;
-        for (int k = 0; k < 8; ++k) {
-            int lo_i = k < 4 ? 0 : k - 3, hi_i = k < 4 ? k : 3;
-            for (int i = lo_i; i <= hi_i; ++i) {
-                u128 p = (u128)l[i] * o.l[k - i];
-                acc += p;
-                if (acc < p) ++hi;
-            }
-            t[k] = (u64)acc;
-            acc = (acc >> 64) | ((u128)hi << 64);
-            hi = 0;
-            if (k == 7) break;
-        }
-        // word-wise Montgomery reduction of t[0..8)
-        u64 extra = 0;
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         for (int i = 0; i < 4; ++i) {
-            u64 m = t[i] * P::INV;
-            u128 c = 0;
-            for (int j = 0; j < 4; ++j) {
-                c += (u128)m * P::M[j] + t[i + j];
-                t[i + j] = (u64)c;
-                c >>= 64;
-            }
-            for (int j = i + 4; j < 8 && c; ++j) {
-                c += t[j];
-                t[j] = (u64)c;
-                c >>= 64;
-            }
-            extra += (u64)c;
+            const u64 a = l[i];
+            u128 c = (u128)a * o.l[0] + t0;
+            t0 = (u64)c;
+            c = (c >> 64) + (u128)a * o.l[1] + t1;
+            t1 = (u64)c;
+            c = (c >> 64) + (u128)a * o.l[2] + t2;
+            t2 = (u64)c;
+            c = (c >> 64) + (u128)a * o.l[3] + t3;
+            t3 = (u64)c;
+            c = (c >> 64) + t4;
+            t4 = (u64)c;
+            const u64 t5 = (u64)(c >> 64);
+            const u64 m = t0 * P::INV;  // t + m*M = 0 mod 2^64
+            c = (u128)m * P::M[0] + t0;
+            c = (c >> 64) + (u128)m * P::M[1] + t1;
+            t0 = (u64)c;
+            c = (c >> 64) + (u128)m * P::M[2] + t2;
+            t1 = (u64)c;
+            c = (c >> 64) + (u128)m * P::M[3] + t3;
+            t2 = (u64)c;
+            c = (c >> 64) + t4;
+            t3 = (u64)c;
+            t4 = (u64)(c >> 64) + t5;
         }
-        Fp r{{t[4], t[5], t[6], t[7]}};
-        if (extra || geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
+        Fp r{{t0, t1, t2, t3}};
+        if (t4 || geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
         return r;
     }
     Fp sqr() const { return *this * *this; }

@@ -53,6 +53,16 @@ struct MsmPlan {
     int c;        // window bits
     int W;        // windows = ceil(256 / c)
     uint32_t B;   // buckets per window = 2^(c-1)
+    int batch;    // MSMs sharing the launch sequence (their windows are laid side by side: W * batch in all)
+    int w0, w1;   // windows [w0, w1) of 0..W are computed (a window-sharded partial); the result carries 2^(c*w0)
+};
+constexpr int MSM_MAX_BATCH = 8;
+// the members of a batched launch: same n, one scalar array and one base offset (in points) each
+struct MsmBatch {
+    int count = 1;
+    const uint64_t *scalars[MSM_MAX_BATCH] = {};
+    uint32_t base_off[MSM_MAX_BATCH] = {};
+    int part = 0, parts = 1;  // window shard: this launch computes windows [part*W/parts, (part+1)*W/parts)
 };
 MsmPlan msm_plan(size_t n, int forced_c);
 
@@ -70,16 +80,22 @@ struct MsmWorkspace {
     uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
-    size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0;
+    size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0, cap_hist = 0, cap_windows = 0;
     MsmPlan plan{};          // plan of the MSM in flight on this slot
     bool in_flight = false;
     // hipGraph of the launch sequence, replayed while the same (bases, scalars, n, form, window) repeats
     struct GraphKey {
-        const void *bases = nullptr, *scalars = nullptr;
+        const void *bases = nullptr;
+        MsmBatch members;
         size_t n = 0;
         int mont = 0, c = 0, span = 0;
         bool operator==(const GraphKey &o) const {
-            return bases == o.bases && scalars == o.scalars && n == o.n && mont == o.mont && c == o.c && span == o.span;
+            if (!(bases == o.bases && n == o.n && mont == o.mont && c == o.c && span == o.span && members.count == o.members.count &&
+                  members.part == o.members.part && members.parts == o.members.parts))
+                return false;
+            for (int b = 0; b < members.count; ++b)
+                if (members.scalars[b] != o.members.scalars[b] || members.base_off[b] != o.members.base_off[b]) return false;
+            return true;
         }
     };
     GraphKey seen_key, graph_key;
@@ -101,6 +117,7 @@ struct halo_ctx {
     halo::Profiler prof;
     int window_bits = 0;
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
+    int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
     // scratch for host-pointer entry points
@@ -134,6 +151,9 @@ void msm_workspace_free(halo_ctx *ctx);
 // asynchronous halves of msm_run on workspace/stream `slot`
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n);
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out);
+// the same for `members.count` MSMs of n points each issued as ONE launch sequence; out[count]
+int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const MsmBatch &members, bool scalars_mont, size_t n);
+int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
 // bases: native affine table (20 words per point)
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);

@@ -41,6 +41,9 @@ MsmPlan msm_plan(size_t n, int forced_c) {
     p.c = c;
     p.W = (256 + c - 1) / c;
     p.B = 1u << (c - 1);
+    p.batch = 1;
+    p.w0 = 0;
+    p.w1 = p.W;
     return p;
 }
 
@@ -64,7 +67,8 @@ HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c
 // with the sign set cannot occur: negative digits have magnitude <= B - 1).  Layout [w][i].
 constexpr uint32_t DIGIT_NONE = 0xFFFFu;
 
-__global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int W,
+// Windows [w0, w1) are written (a window shard still walks the carry chain from window 0).
+__global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int w0, int w1,
                                                     uint32_t B, uint16_t *__restrict__ digits) {
     __shared__ uint32_t sw[256 * 9];
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -76,9 +80,9 @@ __global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
     uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
+    for (int w = 0; w < w1; w++) {
         Digit d = next_digit(my, w, c, B, carry);
-        digits[(size_t)w * n + i] = (uint16_t)(d.mag ? ((d.mag - 1) | (d.neg << 15)) : DIGIT_NONE);
+        if (w >= w0) digits[(size_t)(w - w0) * n + i] = (uint16_t)(d.mag ? ((d.mag - 1) | (d.neg << 15)) : DIGIT_NONE);
     }
 }
 
@@ -116,12 +120,14 @@ __global__ __launch_bounds__(256) void k_msm_colsum(uint32_t *__restrict__ hist,
     }
     counts[g] = run;
 }
+struct MemberOffsets { uint32_t v[MSM_MAX_BATCH]; };
 __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
                                                       uint32_t chunk_len, const uint32_t *__restrict__ hist,
                                                       const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
-                                                      uint32_t *__restrict__ sorted) {
+                                                      uint32_t W_member, MemberOffsets offs, uint32_t *__restrict__ sorted) {
     extern __shared__ uint32_t lds[];
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    uint32_t off = offs.v[w / W_member];  // this window's member reads its bases from point index `off` on
     const uint32_t *pre = hist + ((size_t)w * nchunks + chunk) * B;
     for (uint32_t b = threadIdx.x; b < B; b += 1024) {
         uint32_t g = w * B + b;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict
         uint32_t d = dg[i];
         if (d != DIGIT_NONE) {
             uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
-            sorted[pos] = i | ((d >> 15) << 31);
+            sorted[pos] = (i + off) | ((d >> 15) << 31);
         }
     }
 }
@@ -632,29 +638,35 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n,
 // ------------------------------------------------------------------------------ workspace
 static size_t max_counts() { return (size_t)16 * 32768; }  // c = 16 is the largest W*B over c in [4, 16]
 
-int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
-    MsmWorkspace &ws = ctx->wss[slot];
-    if (n < 64) n = 64;
-    ws.cap_n = n;
-    // sorted entries: n * W; the automatic plan has W <= 32 for n >= 4096 (c >= 8) and W <= 64 below
-    size_t srt = n >= 4096 ? n * 32 : n * 64;
-    ws.cap_counts = max_counts();
-    ws.cap_sorted = srt;
+struct WorkspaceNeed {
+    size_t n, counts, sorted, tasks, hist, windows;
+};
+static void workspace_release(MsmWorkspace &ws) {
+    uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
+    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff,
+                       ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
+    for (auto p : p64) (void)hipFree(p);
+    for (auto p : p32) (void)hipFree(p);
+    if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
+    if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
+    ws = MsmWorkspace();
+}
+static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
+    ws.cap_n = need.n;
+    ws.cap_counts = need.counts;
+    ws.cap_sorted = need.sorted;
+    ws.cap_tasks = need.tasks;
+    ws.cap_hist = need.hist;
+    ws.cap_windows = need.windows;
     // the LDS histograms need up to 128 KiB of dynamic LDS per block (160 KiB per CU on gfx950)
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
-    HALO_HIP(hipMalloc(&ws.d_hist, (size_t)256 * 32768 * 4 + ws.cap_counts * 4));  // [w][chunk][b], W * nchunks <= 256
+    HALO_HIP(hipMalloc(&ws.d_hist, ws.cap_hist * 4));          // [w][chunk][b]
     HALO_HIP(hipMalloc(&ws.d_counts, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_starts, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
-    // tasks <= non-empty buckets + entries / KMAX
-    {   // tasks: one per non-empty bucket plus entries / kmax (kmax = 16 only below 2^18 points, W <= 32 there)
-        size_t small = ws.cap_sorted < ((size_t)1 << 23) ? ws.cap_sorted : ((size_t)1 << 23);
-        size_t extra = ws.cap_sorted / KMAX > small / 16 ? ws.cap_sorted / KMAX : small / 16;
-        ws.cap_tasks = ws.cap_counts + extra + 1;
-    }
     HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_ntask, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
@@ -663,23 +675,30 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     HALO_HIP(hipMalloc(&ws.d_meta, 1024));
     HALO_HIP(hipMalloc(&ws.d_task_g, ws.cap_tasks * 4));
     HALO_HIP(hipMalloc(&ws.d_order, ws.cap_tasks * 4));
-    HALO_HIP(hipMalloc(&ws.d_seg, (size_t)64 * 64 * 2 * XYZZ_WORDS * 4));
-    HALO_HIP(hipMalloc(&ws.d_winsum, (size_t)64 * 12 * 8));
-    HALO_HIP(hipHostMalloc(&ws.h_winsum, (size_t)64 * 12 * 8));
+    HALO_HIP(hipMalloc(&ws.d_seg, ws.cap_windows * 64 * 2 * XYZZ_WORDS * 4));
+    HALO_HIP(hipMalloc(&ws.d_winsum, ws.cap_windows * 12 * 8));
+    HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8));
     return HALO_OK;
 }
-void msm_workspace_free(halo_ctx *ctx) {
-    for (int slot = 0; slot < HALO_SLOTS; ++slot) {
-        MsmWorkspace &ws = ctx->wss[slot];
-        uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
-        uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff,
-                           ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
-        for (auto p : p64) (void)hipFree(p);
-        for (auto p : p32) (void)hipFree(p);
-        if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
-        if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
-        ws = MsmWorkspace();
+// capacity for any single MSM of up to n points, whatever the window size
+int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
+    if (n < 64) n = 64;
+    WorkspaceNeed need;
+    need.n = n;
+    // sorted entries: n * W; the automatic plan has W <= 32 for n >= 4096 (c >= 8) and W <= 64 below
+    need.sorted = n >= 4096 ? n * 32 : n * 64;
+    need.counts = max_counts();
+    {   // tasks: one per non-empty bucket plus entries / kmax (kmax = 16 only below 2^18 points, W <= 32 there)
+        size_t small = need.sorted < ((size_t)1 << 23) ? need.sorted : ((size_t)1 << 23);
+        size_t extra = need.sorted / KMAX > small / 16 ? need.sorted / KMAX : small / 16;
+        need.tasks = need.counts + extra + 1;
     }
+    need.hist = (size_t)256 * 32768 + need.counts;  // W * nchunks <= 256 blocks of B <= 32768 counters
+    need.windows = 64;
+    return workspace_alloc(ctx->wss[slot], need);
+}
+void msm_workspace_free(halo_ctx *ctx) {
+    for (int slot = 0; slot < HALO_SLOTS; ++slot) workspace_release(ctx->wss[slot]);
 }
 
 // ------------------------------------------------------------------------------ driver
@@ -689,7 +708,7 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
     return msm_finish(ctx, 0, out);
 }
 
-int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n);
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n);
 
 struct StreamGuard {  // the launch macro uses ctx->stream
     halo_ctx *ctx;
@@ -698,23 +717,71 @@ struct StreamGuard {  // the launch macro uses ctx->stream
     ~StreamGuard() { ctx->stream = saved; }
 };
 
+static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) { return ctx->task_len > 0 ? (uint32_t)ctx->task_len : n >= ((size_t)1 << 18) ? KMAX : 16u; }
+
+// what a batch of `count` MSMs of n points needs beyond the slot's current capacity (0 = fits)
+static bool batch_need(const halo_ctx *ctx, const MsmWorkspace &ws, size_t n, int count, WorkspaceNeed &need) {
+    MsmPlan p = msm_plan(n, ctx->window_bits);
+    size_t Wt = (size_t)p.W * count, total = Wt * p.B, sorted = n * Wt;
+    size_t hist = (Wt > 256 ? Wt : 256) * (size_t)p.B;
+    size_t tasks = total + sorted / msm_kmax(ctx, n) + 1;
+    bool grow = n > ws.cap_n || total > ws.cap_counts || sorted > ws.cap_sorted || hist > ws.cap_hist || Wt > ws.cap_windows ||
+                tasks > ws.cap_tasks;
+    need.n = n > ws.cap_n ? n : ws.cap_n;
+    need.counts = total > ws.cap_counts ? total : ws.cap_counts;
+    need.sorted = sorted > ws.cap_sorted ? sorted : ws.cap_sorted;
+    need.hist = hist > ws.cap_hist ? hist : ws.cap_hist;
+    need.windows = Wt > ws.cap_windows ? Wt : ws.cap_windows;
+    need.tasks = tasks > ws.cap_tasks ? tasks : ws.cap_tasks;
+    return grow;
+}
+
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
+    MsmBatch one;
+    one.count = 1;
+    one.scalars[0] = d_scalars;
+    return msm_enqueue_batch(ctx, slot, d_bases, one, mont, n);
+}
+
+int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
     if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
+    if (members.count < 1 || members.count > MSM_MAX_BATCH) { set_error("msm: batch size must be in [1, 8]"); return HALO_E_ARG; }
     if (!ctx->wss[slot].d_counts) {
         int rc = msm_workspace_alloc(ctx, ctx->wss[0].cap_n, slot);
         if (rc) return rc;
     }
     MsmWorkspace &ws = ctx->wss[slot];
     if (ws.in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
-    ws.plan = MsmPlan{0, 0, 0};
+    ws.plan = MsmPlan{0, 0, 0, members.count, 0, 0};
+    if (members.parts < 1 || members.part < 0 || members.part >= members.parts) { set_error("msm: window shard out of range"); return HALO_E_ARG; }
     if (n == 0) { ws.in_flight = true; return HALO_OK; }
+    if (members.parts > 1) {  // a shard that owns no window (more shards than windows) contributes the point at infinity
+        MsmPlan p = msm_plan(n, ctx->window_bits);
+        if (p.W * members.part / members.parts == p.W * (members.part + 1) / members.parts) { ws.in_flight = true; return HALO_OK; }
+    }
+    {
+        // A batch lays the members' windows side by side and a forced task length multiplies the tasks: grow
+        // this slot's workspace when the launch needs more room than a single automatic-plan MSM of the
+        // context's size (the slot is idle here and its stream is drained).
+        MsmPlan p = msm_plan(n, ctx->window_bits);
+        if ((size_t)p.W * members.count * p.B > ((size_t)1 << 22)) {
+            set_error("msm: batch too large for this window size (windows * batch * buckets <= 2^22)");
+            return HALO_E_ARG;
+        }
+        WorkspaceNeed need;
+        if ((members.count > 1 || ctx->task_len > 0) && batch_need(ctx, ws, n, members.count, need)) {
+            workspace_release(ws);
+            int rc = workspace_alloc(ws, need);
+            if (rc) return rc;
+        }
+    }
     StreamGuard guard(ctx, ctx->streams[slot]);
     // The launch sequence below is fixed for a given (bases, scalars, n, form, window): the second
     // time the same key arrives it is captured into a hipGraph, afterwards one graph launch replaces
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.scalars = d_scalars; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span;
+    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len;
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     if (graphs && ws.graph_exec && key == ws.graph_key) {
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
@@ -725,7 +792,7 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
     bool capture = graphs && key == ws.seen_key;
     ws.seen_key = key;
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
-    int rc = msm_enqueue_launches(ctx, ws, d_bases, d_scalars, mont, n);
+    int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n);
     if (capture) {
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(ctx->streams[slot], &graph);
@@ -744,22 +811,38 @@ int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t
     return HALO_OK;
 }
 
-// the launch sequence proper (recorded into a graph when the stream is capturing); sets ws.plan
-int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
+// the launch sequence proper (recorded into a graph when the stream is capturing); sets ws.plan.
+// Wt = W * batch windows go through the sort / accumulate / reduce kernels as if they belonged to one MSM;
+// only the recode (one scalar array per member) and the scatter (one base offset per member) know better.
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
     MsmPlan p = msm_plan(n, ctx->window_bits);
-    size_t total = (size_t)p.W * p.B;
-    if (total > ws.cap_counts || n * (size_t)p.W > ws.cap_sorted) { set_error("msm: window plan exceeds workspace"); return HALO_E_ARG; }
+    p.batch = members.count;
+    p.w0 = p.W * members.part / members.parts;
+    p.w1 = p.W * (members.part + 1) / members.parts;
+    uint32_t Wm = (uint32_t)(p.w1 - p.w0);  // windows per member in this launch
+    uint32_t Wt = Wm * (uint32_t)p.batch;
+    size_t total = (size_t)Wt * p.B;
+    if (total > ws.cap_counts || n * (size_t)Wt > ws.cap_sorted || Wt > ws.cap_windows) {
+        set_error("msm: window plan exceeds workspace");
+        return HALO_E_ARG;
+    }
     hipStream_t s = ctx->stream;
     dim3 gridn((unsigned)((n + 255) / 256)), b256(256);
-    uint16_t *d_digits = reinterpret_cast<uint16_t *>(ws.d_canon);  // n * W * 2 bytes
-    HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, gridn, b256, 0, d_scalars, mont ? 1 : 0, (uint32_t)n, p.c, p.W, p.B, d_digits);
+    uint16_t *d_digits = reinterpret_cast<uint16_t *>(ws.d_canon);  // n * Wt * 2 bytes, layout [member][w][i]
+    MemberOffsets offs{};
+    for (int b = 0; b < p.batch; ++b) {
+        offs.v[b] = members.base_off[b];
+        HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, gridn, b256, 0, members.scalars[b], mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
+                    d_digits + (size_t)b * Wm * n);
+    }
     // one block per (window, chunk): about one block per CU, chunks of at least 1024 scalars
-    uint32_t nchunks = 256u / (uint32_t)p.W;
+    uint32_t nchunks = 256u / Wt;
     if (nchunks < 1) nchunks = 1;
     while (nchunks > 1 && (n + nchunks - 1) / nchunks < 1024) nchunks--;
+    if ((size_t)Wt * nchunks * p.B > ws.cap_hist) { set_error("msm: window plan exceeds workspace"); return HALO_E_ARG; }
     uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
-    dim3 gridh((unsigned)(p.W * nchunks)), b1024(1024);
+    dim3 gridh((unsigned)(Wt * nchunks)), b1024(1024);
     size_t lds_bytes = (size_t)p.B * 4;
     HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist);
     HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
@@ -768,17 +851,17 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
     HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
-                ws.d_starts, ws.d_blockoff, ws.d_sorted);
+                ws.d_starts, ws.d_blockoff, Wm, offs, ws.d_sorted);
     dim3 gridb((unsigned)((total + 255) / 256));
     HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
     // chain bound per lane: 64 where the launch is throughput-bound, 16 where it is latency-bound
-    uint32_t kmax = n >= ((size_t)1 << 18) ? KMAX : 16u;
+    uint32_t kmax = msm_kmax(ctx, n);
     HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, kmax, ws.d_ntask);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
     HALO_LAUNCH(ctx, "k_msm_task_meta", k_msm_task_meta, gridb, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, (uint32_t)total, ws.d_meta,
                 ws.d_biglist);
-    size_t max_tasks = total + n * (size_t)p.W / kmax + 1;
+    size_t max_tasks = total + n * (size_t)Wt / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
     HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax, ws.d_meta,
@@ -806,33 +889,41 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         nseg = p.B / (64 * L);
     }
     while ((1u << logL) < L) logL++;
-    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(p.W * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
+    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(Wt * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
-    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)p.W), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
+    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)Wt), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)p.W * 96, hipMemcpyDeviceToHost, s));
+    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
     ws.plan = p;
     return HALO_OK;
 }
 
-int msm_finish(halo_ctx *ctx, int slot, host::Point *out) {
-    *out = host::Point::infinity();
+int msm_finish(halo_ctx *ctx, int slot, host::Point *out) { return msm_finish_batch(ctx, slot, out, 1); }
+
+int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {
+    for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
     if (slot < 0 || slot >= HALO_SLOTS || !ctx->wss[slot].in_flight) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
     MsmWorkspace &ws = ctx->wss[slot];
-    ws.in_flight = false;
     MsmPlan p = ws.plan;
-    if (p.W == 0) return HALO_OK;  // n == 0
+    if (p.batch != count) { set_error("msm: this slot holds a batch of a different size"); return HALO_E_ARG; }
+    ws.in_flight = false;
+    if (p.W == 0) return HALO_OK;  // n == 0, or a window shard without windows
     HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
     bool others = false;
     for (int k = 0; k < HALO_SLOTS; ++k) others = others || ctx->wss[k].in_flight;
     if (ctx->prof.on && !others) ctx->prof.collect();
-    host::Point acc = host::Point::infinity();
-    for (int w = p.W - 1; w >= 0; --w) {
+    int Wm = p.w1 - p.w0;
+    for (int b = 0; b < count; ++b) {
+        host::Point acc = host::Point::infinity();
+        for (int w = Wm - 1; w >= 0; --w) {
+            if (!acc.is_inf())
+                for (int k = 0; k < p.c; ++k) acc = acc.dbl();
+            acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)b * Wm + w));
+        }
         if (!acc.is_inf())
-            for (int k = 0; k < p.c; ++k) acc = acc.dbl();
-        acc = acc + host::Point::load(ws.h_winsum + 12 * (size_t)w);
+            for (int k = 0; k < p.c * p.w0; ++k) acc = acc.dbl();  // a window shard's weight 2^(c * w0)
+        out[b] = acc;
     }
-    *out = acc;
     return HALO_OK;
 }
 

@@ -1,12 +1,19 @@
-"""Index-sharded MSM across the GPUs of one node (BASELINE config 5).
+"""Sharded MSM across the GPUs of one node (BASELINE config 5).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI, "gloo" on CPU for
-tests).  An MSM is a sum of independent terms, so rank r owns the index block
-[r*n/P, (r+1)*n/P) of bases and scalars, reduces it to ONE point with the local Pippenger
-pipeline, and the only exchange step is an all-gather of P x 96 bytes followed by P-1 point
-additions in fixed rank order on every rank.  (RCCL has no user-defined reduction operator, so
-an elliptic-curve sum cannot be an all-reduce.)  The payload is latency-, not bandwidth-bound:
-one collective per MSM and nothing else crosses the fabric.
+tests).  An MSM is a sum of independent terms, and it can be cut two ways; either way a rank
+reduces its share to ONE point with the local Pippenger pipeline, and the only exchange step is an
+all-gather of P x 96 bytes followed by P-1 point additions in fixed rank order on every rank.
+(RCCL has no user-defined reduction operator, so an elliptic-curve sum cannot be an all-reduce.)
+The payload is latency-, not bandwidth-bound: one collective per batch of MSMs and nothing else
+crosses the fabric.
+
+* index shards (shard_range): rank r owns the index block [r*n/P, (r+1)*n/P) of bases and scalars.
+  Memory and upload traffic are 1/P per rank, but each rank runs a SMALLER Pippenger, which costs more
+  per point (its 2^(c-1) buckets per window are reduced for n/P instead of n points): right for n >= 2^22.
+* window shards (window_range, halo_msm_dev_begin_part): every rank keeps the whole key and all scalars
+  (160 MiB at n = 2^20 of 288 GiB) and computes the Pippenger windows [r*W/P, (r+1)*W/P) of the full-size
+  MSM: exactly 1/P of the single-GPU bucket work.  This is what bench.py uses for n = 2^20.
 """
 from __future__ import annotations
 
@@ -18,6 +25,11 @@ def shard_range(n: int, rank: int, world: int):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def window_range(W: int, rank: int, world: int):
+    """The scalar windows [w0, w1) of W that window shard `rank` of `world` computes (the library's own split)."""
+    return W * rank // world, W * (rank + 1) // world
 
 
 class ShardedMsm:

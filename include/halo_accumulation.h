@@ -73,6 +73,22 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
  * At most one MSM per slot in flight; the scalars must stay untouched until end(). */
 int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int scalars_are_mont);
 int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out_jac[12]);
+/* Window shard `part` of `parts`: the same MSM restricted to the scalar windows [part*W/parts, (part+1)*W/parts)
+ * of the W Pippenger windows, already weighted by its power of two -- the results of all parts (any order,
+ * any GPU holding the same bases and scalars) add up to halo_msm_dev's point (halo_point_sum).  A GPU then
+ * does 1/parts of the bucket work at the bucket efficiency of the full-size MSM, which index-sharding an
+ * n <= 2^21 MSM does not.  end() is halo_msm_dev_end. */
+int halo_msm_dev_begin_part(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int scalars_are_mont, int part,
+                            int parts);
+/* Batched form: `batch` (1..8) independent MSMs over the same bases G[off .. off+n), one resident scalar
+ * array each (d_scalars[b]), issued as ONE launch sequence on `slot`: the members' windows go through the
+ * sort / bucket / window-sum kernels side by side, which fills the GPU where one launch alone is
+ * latency-bound (a rank's window shard of a sharded MSM).  part/parts as in halo_msm_dev_begin_part (0, 1 =
+ * whole MSMs).  end() writes batch x 12 limbs; member b's result is bit-identical to the unbatched call on
+ * d_scalars[b].  The slot's workspace grows on first use. */
+int halo_msm_dev_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *const *d_scalars, size_t batch,
+                             int scalars_are_mont, int part, int parts);
+int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out_jac);
 /* point_dot (group.rs:18-21): arbitrary Jacobian points (m x 12 limbs); they are brought to
  * affine with one batched inversion instead of the reference's m separate ones. */
 int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out_jac[12]);
@@ -189,6 +205,8 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 int halo_set_window_bits(halo_ctx *ctx, int c);
 /* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */
 int halo_set_reduce_span(halo_ctx *ctx, int span);
+/* MSM tuning: longest chain of mixed additions one lane runs in the bucket kernel (0 = automatic; 8, 16, 32, 64) */
+int halo_set_task_len(halo_ctx *ctx, int len);
 
 /* ---- primitive hooks used by the parity tests (elementwise over n) ----------------------- */
 /* host-only: GLV split of the fold scalar (host_math.hpp): out = s1[5] | s2[5] | e[3] | neg12 | nbits | 0 */

@@ -296,6 +296,90 @@ def test_msm_pipelined_slots_agree(ctx1m):
         ctx1m.msm_dev_end(0)  # nothing in flight
 
 
+@pytest.mark.parametrize("n,batch", [(1, 2), (63, 3), (1000, 8), (4096, 2), (16384, 4), (16384, 8)])
+def test_msm_batch_members_equal_single_msms(hal, ctx16k, urs4096, n, batch):
+    """halo_msm_dev_batch_*: every member of a batched launch equals the oracle / the single MSM on its scalars."""
+    import torch
+    scs = [orc.rng_scalars(7000 + 31 * n + i, n)[0] for i in range(batch)]
+    if batch > 2:  # adversarial members: all r-1, all zero
+        scs[1] = np.tile(orc.fr_to_mont(0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001 - 1), (n, 1))
+        scs[2] = np.zeros((n, 4), dtype=np.uint64)
+    ds = [torch.from_numpy(np.ascontiguousarray(s).view(np.int64)).cuda() for s in scs]
+    if n <= 4096:
+        gs = urs4096[:n]
+        want = [orc.msm_affine(gs, s).tolist() for s in scs]
+    else:
+        want = [ctx16k.msm_dev(d.data_ptr(), n).tolist() for d in ds]
+    for rep in range(3):  # third repetition replays the captured graph
+        ctx16k.msm_dev_batch_begin(2, [d.data_ptr() for d in ds], n)
+        got = ctx16k.msm_dev_batch_end(2, batch)
+        assert got.tolist() == want
+    # the slot goes back to single MSMs afterwards, and a non-zero base offset works
+    ctx16k.msm_dev_begin(2, ds[0].data_ptr(), n)
+    assert ctx16k.msm_dev_end(2).tolist() == want[0]
+    if n == 1000:
+        ctx16k.msm_dev_batch_begin(1, [d.data_ptr() for d in ds[:2]], n, off=3000)
+        got = ctx16k.msm_dev_batch_end(1, 2)
+        gs = urs4096[3000:4000]
+        assert got.tolist() == [orc.msm_affine(gs, s).tolist() for s in scs[:2]]
+
+
+@pytest.mark.parametrize("n,parts", [(1000, 2), (1000, 5), (4096, 8), (16384, 3), (16384, 64)])
+def test_msm_window_shards_sum_to_the_msm(hal, ctx16k, urs4096, n, parts):
+    """halo_msm_dev_begin_part: the window shards' partial points add up to the full MSM (more shards than
+    windows: the surplus shards return infinity)."""
+    import torch
+    sc = orc.rng_scalars(9100 + n + parts, n)[0]
+    sc[0] = orc.fr_to_mont(0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001 - 1)
+    d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    want = orc.msm_affine(urs4096[:n], sc).tolist() if n <= 4096 else ctx16k.msm_dev(d.data_ptr(), n).tolist()
+    partials = []
+    for part in range(parts):
+        slot = part % 4
+        ctx16k.msm_dev_begin(slot, d.data_ptr(), n, part=part, parts=parts)
+        partials.append(ctx16k.msm_dev_end(slot))
+    assert hal.point_sum(np.stack(partials)).tolist() == want
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm_dev_begin(0, d.data_ptr(), n, part=parts, parts=parts)
+
+
+def test_msm_window_shards_2_20(hal, ctx1m):
+    import torch
+    n = 1 << 20
+    d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    ctx1m.rng_scalars_dev(0x48414C4F00000002, n, d.data_ptr())
+    want = ctx1m.msm_dev(d.data_ptr(), n).tolist()
+    for parts in (2, 8):
+        partials = []
+        for part in range(parts):
+            ctx1m.msm_dev_begin(part % 4, d.data_ptr(), n, part=part, parts=parts)
+            if part % 4 == 3:
+                partials += [ctx1m.msm_dev_end(s) for s in range(4)]
+        partials += [ctx1m.msm_dev_end(s) for s in range(parts % 4)]
+        assert hal.point_sum(np.stack(partials)).tolist() == want
+
+
+def test_msm_batch_2_18_and_misuse(hal, ctx1m):
+    import torch
+    n = 1 << 18
+    ds = []
+    for i in range(4):
+        d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        ctx1m.rng_scalars_dev(555 + i, n, d.data_ptr())
+        ds.append(d)
+    want = [ctx1m.msm_dev(d.data_ptr(), n).tolist() for d in ds]
+    ctx1m.msm_dev_batch_begin(0, [d.data_ptr() for d in ds], n)
+    ctx1m.msm_dev_batch_begin(3, [d.data_ptr() for d in ds[::-1]], n)
+    assert ctx1m.msm_dev_batch_end(3, 4).tolist() == want[::-1]
+    with pytest.raises(hal.HaloError):
+        ctx1m.msm_dev_batch_end(0, 2)      # wrong batch size: reported, the batch stays in flight
+    assert ctx1m.msm_dev_batch_end(0, 4).tolist() == want
+    with pytest.raises(hal.HaloError):
+        ctx1m.msm_dev_batch_begin(0, [d.data_ptr() for d in ds] * 3, n)   # 12 members
+    with pytest.raises(hal.HaloError):
+        ctx1m.msm_dev_batch_begin(0, [ds[0].data_ptr(), 0], n)            # null member
+
+
 def test_device_rng_matches_stream(ctx16k):
     """halo_rng_scalars_dev == the sequential SplitMix64 stream the oracle and the tests use."""
     import torch

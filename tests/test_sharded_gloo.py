@@ -45,6 +45,51 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
+def _window_worker(rank, world, port, n, q):
+    """window shards: every rank holds the whole key, its partial covers its scalar windows only"""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd.sharded import ShardedMsm, window_range
+    import orc
+    gs = orc.urs_affine(2, n)
+    sc, _ = orc.rng_scalars(0x48414C4F00000005, n)
+    c, W = 16, 16
+    w0, w1 = window_range(W, rank, world)
+    ints = [orc.fr_from_mont(x) for x in sc]
+    mine = [((v >> (c * w0)) & ((1 << (c * (w1 - w0))) - 1)) << (c * w0) for v in ints]  # this rank's windows of every scalar
+    msm = ShardedMsm(lambda: orc.msm_affine(gs, orc.scalars_to_mont(mine)), h._lib.point_sum)
+    q.put((rank, msm().tolist(), (w0, w1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_sharded_msm_gloo(world):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    n = 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_window_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = orc.msm_affine(orc.urs_affine(2, n), orc.rng_scalars(0x48414C4F00000005, n)[0]).tolist()
+    ranges = sorted(r[2] for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 16 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for rank, out, _ in res:
+        assert out == want, "rank %d disagrees" % rank
+
+
 @pytest.mark.parametrize("world,n", [(2, 256), (3, 101)])
 def test_sharded_msm_gloo(world, n):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -12,6 +12,7 @@ if len(sys.argv) > 4:
     ctx.set_window_bits(int(sys.argv[4]))
 if len(sys.argv) > 5:
     ctx.set_reduce_span(int(sys.argv[5]))
+parts = int(os.environ.get("PARTS", "1"))
 d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(2, n, d.data_ptr())
 def run(K2):
@@ -19,7 +20,7 @@ def run(K2):
     for i in range(K2):
         if len(pend) == depth:
             ctx.msm_dev_end(pend.pop(0))
-        ctx.msm_dev_begin(i % depth, d.data_ptr(), n)
+        ctx.msm_dev_begin(i % depth, d.data_ptr(), n, part=parts - 1, parts=parts)
         pend.append(i % depth)
     while pend:
         ctx.msm_dev_end(pend.pop(0))
