@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--depth", type=int, default=4, help="launch sequences in flight (1..4)")
     ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one GPU, 4 on several)")

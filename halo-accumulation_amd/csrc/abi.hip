@@ -514,14 +514,13 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     halo_ctx *ctx = st->ctx;
     if (st->m < 2) { set_error("ipa_round_lr: no rounds left"); return HALO_E_ARG; }
     size_t m = st->m / 2;
-    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207)
-    int rc = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
-    if (rc) return rc;
+    int rc;
     host::Point Lp, Rp;
-    // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; slot 1's stream first waits
+    // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; the other streams first wait
     // for everything queued on stream 0 (the previous round's folds)
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
+    HALO_HIP(hipStreamWaitEvent(ctx->streams[2], st->ev, 0));
     if (st->nofold) {
         rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
         if (rc) return rc;
@@ -536,10 +535,16 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         rc = msm_enqueue(ctx, 1, st->d_G + 32 * m, st->d_c, true, m);
     }
     if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
+    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream while the MSMs run
+    hipStream_t saved = ctx->stream;
+    ctx->stream = ctx->streams[2];
+    int rcd = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
+    ctx->stream = saved;
     rc = msm_finish(ctx, 0, &Lp);
     int rc2 = msm_finish(ctx, 1, &Rp);
     if (rc) return rc;
     if (rc2) return rc2;
+    if (rcd) return rcd;
     *Lp_out = Lp;
     *Rp_out = Rp;
     return HALO_OK;

@@ -23,7 +23,7 @@ for k, (ms, cnt) in sorted(ctx.prof().items(), key=lambda kv: -kv[1][0]):
     print("   %-22s total %9.3f ms  launches %4d  avg %8.3f ms" % (k, ms, cnt, ms / max(cnt, 1)))
 ctx.prof_enable(False)
 t = time.time(); pi = pcdl.open(ctx, [7], coeffs, C, d, z, w); print("open (unprofiled) %.2f ms" % ((time.time() - t) * 1e3))
-for sw in (1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19):
+for sw in (1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17):
     ctx.set_ipa_switch(sw)
     pcdl.open(ctx, [7], coeffs, C, d, z, w)
     t = time.time(); pi2 = pcdl.open(ctx, [7], coeffs, C, d, z, w)
