@@ -173,6 +173,27 @@ def test_msm_every_window_size(ctx16k, c):
         ctx16k.set_window_bits(0)
 
 
+@pytest.mark.parametrize("span,task_len", [(1, 8), (2, 16), (16, 32), (64, 64), (0, 8)])
+def test_msm_tuning_knobs_do_not_change_results(hal, ctx16k, urs4096, span, task_len):
+    """halo_set_reduce_span / halo_set_task_len only move work around (the workspace grows for short tasks)."""
+    n = 4096
+    sc, _ = orc.rng_scalars(4242 + span, n)
+    sc[:1000] = sc[7]  # a fat bucket in every window: many tasks, the big-combine path
+    want = orc.msm_affine(urs4096, sc).tolist()
+    ctx16k.set_reduce_span(span)
+    ctx16k.set_task_len(task_len)
+    try:
+        for c in (0, 13):
+            ctx16k.set_window_bits(c)
+            assert ctx16k.msm(sc).tolist() == want
+    finally:
+        ctx16k.set_reduce_span(0); ctx16k.set_task_len(0); ctx16k.set_window_bits(0)
+    with pytest.raises(hal.HaloError):
+        ctx16k.set_task_len(12)
+    with pytest.raises(hal.HaloError):
+        ctx16k.set_reduce_span(3)
+
+
 def test_msm_degenerate_inputs(ctx16k):
     n = 4096
     gs = ctx16k.read_bases(0, n)
