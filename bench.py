@@ -168,6 +168,16 @@ def main():
         if world == 1 and args.log_n == 20 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["kernels"].get("k_msm_accumulate", {}).get("traffic_bytes_per_launch")
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+        # VALU view of the same kernel: one mixed XYZZ addition is 1143 v_mad_u64_u32 on the
+        # kernel's hot path (counted in the gfx950 ISA), one per point per window; the issue peak is the measured
+        # 5.26 cycles per wave-instruction (profiles/r01_microbench_instr_throughput.txt) on 4 SIMDs per CU
+        props = torch.cuda.get_device_properties(gpu)
+        plan_w = 16 if args.log_n >= 20 else None
+        valu = None
+        if plan_w and kern_s > 0:
+            wave_mads = batch * (hi - lo) * plan_w / parts * 1143 / 64
+            peak = props.multi_processor_count * 4 * (props.clock_rate * 1e3) / 5.26
+            valu = {"unit": "v_mad_u64_u32 wave-instr/s", "achieved": wave_mads / kern_s, "peak": peak, "frac": wave_mads / kern_s / peak}
         result = {
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
             "value": args.steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,7 +192,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
-                         "algorithmic_bytes": alg_bytes,
+                         "algorithmic_bytes": alg_bytes, "valu": valu,
                          "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
             "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
         }

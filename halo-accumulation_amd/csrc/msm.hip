@@ -90,16 +90,29 @@ __global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__
 // 128 KiB of the CU's 160 KiB).  Block (w, chunk) covers scalars [chunk*len, (chunk+1)*len).
 // hist layout [w][chunk][b] so that every global access is coalesced.
 __global__ __launch_bounds__(1024) void k_msm_hist(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
-                                                   uint32_t chunk_len, uint32_t *__restrict__ hist) {
+                                                   uint32_t chunk_len, int vec, uint32_t *__restrict__ hist) {
     extern __shared__ uint32_t lds[];
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
     for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = 0;
     __syncthreads();
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint16_t *dg = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        uint32_t d = dg[i];
-        if (d != DIGIT_NONE) atomicAdd(&lds[d & 0x7FFFu], 1u);
+    if (vec) {  // n and chunk_len are multiples of 8: eight digits per 16-byte load, eight atomics in flight
+        for (uint32_t i = lo + 8 * threadIdx.x; i < hi; i += 8 * 1024) {
+            uint4 q = *reinterpret_cast<const uint4 *>(dg + i);
+            uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t d0 = v[k] & 0xFFFFu, d1 = v[k] >> 16;
+                if (d0 != DIGIT_NONE) atomicAdd(&lds[d0 & 0x7FFFu], 1u);
+                if (d1 != DIGIT_NONE) atomicAdd(&lds[d1 & 0x7FFFu], 1u);
+            }
+        }
+    } else {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+            uint32_t d = dg[i];
+            if (d != DIGIT_NONE) atomicAdd(&lds[d & 0x7FFFu], 1u);
+        }
     }
     __syncthreads();
     uint32_t *out = hist + ((size_t)w * nchunks + chunk) * B;
@@ -124,7 +137,7 @@ struct MemberOffsets { uint32_t v[MSM_MAX_BATCH]; };
 __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
                                                       uint32_t chunk_len, const uint32_t *__restrict__ hist,
                                                       const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
-                                                      uint32_t W_member, MemberOffsets offs, uint32_t *__restrict__ sorted) {
+                                                      uint32_t W_member, MemberOffsets offs, int vec, uint32_t *__restrict__ sorted) {
     extern __shared__ uint32_t lds[];
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
     uint32_t off = offs.v[w / W_member];  // this window's member reads its bases from point index `off` on
@@ -136,11 +149,29 @@ __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict
     __syncthreads();
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint16_t *dg = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        uint32_t d = dg[i];
-        if (d != DIGIT_NONE) {
-            uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
-            sorted[pos] = (i + off) | ((d >> 15) << 31);
+    if (vec) {
+        for (uint32_t i = lo + 8 * threadIdx.x; i < hi; i += 8 * 1024) {
+            uint4 q = *reinterpret_cast<const uint4 *>(dg + i);
+            uint32_t v[4] = {q.x, q.y, q.z, q.w};
+            uint32_t pos[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t d = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                pos[k] = d != DIGIT_NONE ? atomicAdd(&lds[d & 0x7FFFu], 1u) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t d = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                if (pos[k] != 0xFFFFFFFFu) sorted[pos[k]] = (i + k + off) | ((d >> 15) << 31);
+            }
+        }
+    } else {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+            uint32_t d = dg[i];
+            if (d != DIGIT_NONE) {
+                uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
+                sorted[pos] = (i + off) | ((d >> 15) << 31);
+            }
         }
     }
 }
@@ -842,16 +873,18 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     while (nchunks > 1 && (n + nchunks - 1) / nchunks < 1024) nchunks--;
     if ((size_t)Wt * nchunks * p.B > ws.cap_hist) { set_error("msm: window plan exceeds workspace"); return HALO_E_ARG; }
     uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
+    int vec = n % 8 == 0 ? 1 : 0;  // digit rows stay 16-byte aligned: vector loads of eight digits
+    if (vec) chunk_len = (chunk_len + 7) / 8 * 8;
     dim3 gridh((unsigned)(Wt * nchunks)), b1024(1024);
     size_t lds_bytes = (size_t)p.B * 4;
-    HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist);
+    HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);
     HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
                 ws.d_counts);
     uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
     HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
-                ws.d_starts, ws.d_blockoff, Wm, offs, ws.d_sorted);
+                ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
     dim3 gridb((unsigned)((total + 255) / 256));
     HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
     // chain bound per lane: 64 where the launch is throughput-bound, 16 where it is latency-bound
