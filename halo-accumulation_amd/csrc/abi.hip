@@ -746,12 +746,11 @@ int halo_open_combine(const uint64_t *parts, size_t P, const uint64_t Hp[12], co
     return HALO_OK;
 }
 
-int halo_test_glv_split(const uint64_t xi[4], uint32_t out[16]) {
-    if (!xi || !out) { set_error("glv_split: null pointer"); return HALO_E_ARG; }
-    host::GlvSplit sp = host::glv_split(host::Fr::load(xi));
-    for (int i = 0; i < 5; ++i) { out[i] = sp.s1[i]; out[5 + i] = sp.s2[i]; }
-    out[10] = (uint32_t)sp.e[0]; out[11] = (uint32_t)sp.e[1]; out[12] = (uint32_t)sp.e[2];
-    out[13] = (uint32_t)sp.neg12; out[14] = (uint32_t)sp.nbits; out[15] = 0;
+int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n_out) {
+    if (!xi || !out || !n_out) { set_error("glv_digits: null pointer"); return HALO_E_ARG; }
+    host::GlvDigits dg = host::glv_digits(host::Fr::load(xi));
+    for (int i = 0; i < 144; ++i) out[i] = i < dg.n ? dg.d[i] : 0;
+    *n_out = dg.n;
     return HALO_OK;
 }
 int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out) {

@@ -280,17 +280,18 @@ inline Point small_msm(const std::vector<Point> &pts, const std::vector<Fr> &ks_
     return acc;
 }
 
-// ------------------------------------------------------------------ GLV split for the uniform-scalar fold
+// ------------------------------------------------------------------ GLV digits for the uniform-scalar fold
 // Pallas has the endomorphism phi(x, y) = (beta x, y) = [lambda](x, y), beta^3 = 1 in Fq,
 // lambda^3 = 1 in Fr.  xi = k1 + k2 lambda with |k1|, |k2| < 2^128 (Babai rounding on the short
-// basis (a1, -b1n), (a2, b2)); because P + phi P + phi^2 P = 0 the signs can always be moved so
-// that xi P = s1 T1 + s2 T2 with s1, s2 >= 0 and T1, T2, T1 + T2 each of the form
-// (beta^e x, +-y): a 128-step joint ladder whose three table entries cost two multiplications.
-struct GlvSplit {
-    uint32_t s1[5], s2[5];  // non-negative scalars, < 2^130, little-endian 32-bit words
-    int e[3];               // power of beta for T1, T2, T3 = T1 + T2
-    int neg12;              // 1: T1, T2 carry -y and T3 carries +y; 0: the opposite
-    int nbits;              // max bit length of s1, s2
+// basis (a1, -b1n), (a2, b2)), i.e. xi is the Eisenstein integer z = k1 + k2 w (w^2 + w + 1 = 0).
+// z is then written in base 2 with digits from {0, +-1, +-w, +-w^2}: z = sum_i d_i 2^i.  Every
+// non-zero digit is a unit, and unit * P = (beta^e x, +-y) costs nothing, so xi P is a ~129-step
+// double-and-add whose additions all take a "free" table entry.  z mod 2 fixes the unit up to its
+// sign; the sign is chosen so that the next digit is zero whenever that is possible, which leaves
+// ~0.6 additions per doubling (0.75 for the plain joint binary ladder over k1, k2).
+struct GlvDigits {
+    uint8_t d[144];  // digit codes, least significant first: 0 none, 1..3 = +w^0..+w^2, 4..6 = -w^0..-w^2
+    int n;           // number of digits (<= 132)
 };
 namespace glv_detail {
 inline void mul_limbs(const u64 *a, int na, const u64 *b, int nb, u64 *out /* na + nb */) {
@@ -321,20 +322,26 @@ inline void sub256(u64 r[4], const u64 a[4], const u64 b[4]) {
     u64 borrow = 0;
     for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - b[i] - borrow; r[i] = (u64)d; borrow = (u64)(d >> 64) & 1; }
 }
-inline void add256(u64 r[4], const u64 a[4], const u64 b[4]) {
-    u64 carry = 0;
-    for (int i = 0; i < 4; ++i) { u128 t = (u128)a[i] + b[i] + carry; r[i] = (u64)t; carry = (u64)(t >> 64); }
-}
 inline void mul_lo256(const u64 c[3], const u64 v[2], u64 out[4]) {
     u64 full[5];
     mul_limbs(c, 3, v, 2, full);
     for (int i = 0; i < 4; ++i) out[i] = full[i];
 }
-inline bool negative(const u64 v[4]) { return (v[3] >> 63) != 0; }
-inline void negate(u64 v[4]) { u64 z[4] = {0, 0, 0, 0}; sub256(v, z, v); }
+// 256-bit two's complement helpers
+inline bool is_zero256(const u64 v[4]) { return (v[0] | v[1] | v[2] | v[3]) == 0; }
+inline void add_small(u64 v[4], int s) {  // v += s, s in {-1, 0, 1}
+    if (s > 0) { for (int i = 0; i < 4 && ++v[i] == 0; ++i) {} }
+    if (s < 0) { for (int i = 0; i < 4 && v[i]-- == 0; ++i) {} }
+}
+inline void sar1(u64 v[4]) {  // arithmetic shift right by one
+    u64 sign = v[3] & (1ULL << 63);
+    for (int i = 0; i < 3; ++i) v[i] = (v[i] >> 1) | (v[i + 1] << 63);
+    v[3] = (v[3] >> 1) | sign;
+}
 }  // namespace glv_detail
 
-inline GlvSplit glv_split(const Fr &xi_mont) {
+// k1, k2 (256-bit two's complement, |.| < 2^128) with xi = k1 + k2 lambda (mod r)
+inline void glv_decompose(const Fr &xi_mont, u64 k1[4], u64 k2[4]) {
     using namespace glv_detail;
     static const u64 G1[5] = {0x111f686111afc293ULL, 0xc35fbd4d086862e0ULL, 0x31f0256800000002ULL, 0x4f34e8b2066389a4ULL, 0x2ULL};
     static const u64 G2[5] = {0x4a95a2d972171db4ULL, 0x61afdea68480fa55ULL, 0x32c49e4bffffffffULL, 0x279a745902a2654eULL, 0x1ULL};
@@ -343,7 +350,7 @@ inline GlvSplit glv_split(const Fr &xi_mont) {
     static const u64 A2[2] = {0x8cb1279300000000ULL, 0x49e69d1640a89953ULL};
     static const u64 B2[2] = {0x0c7c095a00000001ULL, 0x93cd3a2c8198e269ULL};
     Fr k = xi_mont.from_mont();
-    u64 c1[3], c2[3], t[4], k1[4], k2[4];
+    u64 c1[3], c2[3], t[4];
     round_shift(k.l, G1, c1);
     round_shift(k.l, G2, c2);
     // k1 = k - c1 a1 - c2 a2 ; k2 = c1 b1n - c2 b2   (mod 2^256, small signed results)
@@ -351,37 +358,74 @@ inline GlvSplit glv_split(const Fr &xi_mont) {
     mul_lo256(c2, A2, t); sub256(k1, k1, t);
     mul_lo256(c1, B1N, k2);
     mul_lo256(c2, B2, t); sub256(k2, k2, t);
-    bool n1 = negative(k1), n2 = negative(k2);
-    if (n1) negate(k1);
-    if (n2) negate(k2);
-    u64 s1[4], s2[4];
-    GlvSplit r;
-    if (!n1 && !n2) {        // k1 P + k2 phi P
-        std::memcpy(s1, k1, 32); std::memcpy(s2, k2, 32);
-        r.e[0] = 0; r.e[1] = 1; r.e[2] = 2; r.neg12 = 0;
-    } else if (!n1 && n2) {  // (k1 + |k2|) P + |k2| phi^2 P
-        add256(s1, k1, k2); std::memcpy(s2, k2, 32);
-        r.e[0] = 0; r.e[1] = 2; r.e[2] = 1; r.neg12 = 0;
-    } else if (n1 && !n2) {  // (|k1| + k2) phi P + |k1| phi^2 P
-        add256(s1, k1, k2); std::memcpy(s2, k1, 32);
-        r.e[0] = 1; r.e[1] = 2; r.e[2] = 0; r.neg12 = 0;
-    } else {                 // |k1| (-P) + |k2| (-phi P)
-        std::memcpy(s1, k1, 32); std::memcpy(s2, k2, 32);
-        r.e[0] = 0; r.e[1] = 1; r.e[2] = 2; r.neg12 = 1;
-    }
-    int nbits = 0;
-    for (int i = 0; i < 5; ++i) {
-        int limb = i / 2, half = i % 2;
-        r.s1[i] = limb < 4 ? (uint32_t)(s1[limb] >> (32 * half)) : 0;
-        r.s2[i] = limb < 4 ? (uint32_t)(s2[limb] >> (32 * half)) : 0;
-        uint32_t both = r.s1[i] | r.s2[i];
-        if (both) {
-            int top = 31;
-            while (!((both >> top) & 1)) --top;
-            nbits = 32 * i + top + 1;
+}
+
+// The sign choices form a tiny search space: whatever signs were taken, the value left after i digits is
+// floor-ish(z / 2^i) plus a bounded offset, so at most a handful (measured: 3) of distinct remainders exist
+// per level.  A level-by-level dynamic program over them finds the expansion with the fewest non-zero
+// digits (~71 of ~127 for a random xi; the greedy "make the next digit zero" rule gives ~77).
+inline GlvDigits glv_digits(const Fr &xi_mont) {
+    using namespace glv_detail;
+    // coordinates (a, b) of the units +1, +w, +w^2 = -1 - w over the basis (1, w); codes 4..6 are their negatives
+    static const int UA[3] = {1, 0, -1}, UB[3] = {0, 1, -1};
+    constexpr int LEVELS = 140, WIDTH = 8;
+    struct State { u64 a[4], b[4]; int cost, parent; uint8_t code; };
+    static thread_local State lv[LEVELS + 1][WIDTH];
+    int count[LEVELS + 1];
+    glv_decompose(xi_mont, lv[0][0].a, lv[0][0].b);
+    lv[0][0].cost = 0; lv[0][0].parent = -1; lv[0][0].code = 0;
+    count[0] = 1;
+    int best_level = -1, best_idx = -1, best_cost = 1 << 30;
+    for (int L = 0; L < LEVELS; ++L) {
+        count[L + 1] = 0;
+        auto push = [&](const u64 a[4], const u64 b[4], int cost, int parent, uint8_t code) {
+            for (int k = 0; k < count[L + 1]; ++k) {
+                State &t = lv[L + 1][k];
+                if (std::memcmp(t.a, a, 32) == 0 && std::memcmp(t.b, b, 32) == 0) {
+                    if (cost < t.cost) { t.cost = cost; t.parent = parent; t.code = code; }
+                    return;
+                }
+            }
+            if (count[L + 1] == WIDTH) return;  // cannot happen (<= 3 remainders per level); keeps the table bounded
+            State &t = lv[L + 1][count[L + 1]++];
+            std::memcpy(t.a, a, 32); std::memcpy(t.b, b, 32);
+            t.cost = cost; t.parent = parent; t.code = code;
+        };
+        bool live = false;
+        for (int k = 0; k < count[L]; ++k) {
+            const State &st = lv[L][k];
+            if (is_zero256(st.a) && is_zero256(st.b)) {
+                if (st.cost < best_cost) { best_cost = st.cost; best_level = L; best_idx = k; }
+                continue;
+            }
+            if (st.cost >= best_cost) continue;  // cannot beat a finished expansion any more
+            live = true;
+            unsigned pa = (unsigned)(st.a[0] & 1), pb = (unsigned)(st.b[0] & 1);
+            u64 a[4], b[4];
+            if (!(pa | pb)) {
+                std::memcpy(a, st.a, 32); std::memcpy(b, st.b, 32);
+                sar1(a); sar1(b);
+                push(a, b, st.cost, k, 0);
+            } else {
+                int e = (pa && pb) ? 2 : (pb ? 1 : 0);  // z = 1, w, 1 + w = -w^2 (mod 2): the unit up to its sign
+                for (int neg = 0; neg < 2; ++neg) {
+                    std::memcpy(a, st.a, 32); std::memcpy(b, st.b, 32);
+                    add_small(a, neg ? UA[e] : -UA[e]);
+                    add_small(b, neg ? UB[e] : -UB[e]);
+                    sar1(a); sar1(b);
+                    push(a, b, st.cost + 1, k, (uint8_t)(e + 1 + 3 * neg));
+                }
+            }
         }
+        if (!live) break;
     }
-    r.nbits = nbits;
+    GlvDigits r;
+    r.n = best_level < 0 ? 0 : best_level;
+    for (int L = best_level, k = best_idx; L > 0; --L) {
+        r.d[L - 1] = lv[L][k].code;
+        k = lv[L][k].parent;
+    }
+    while (r.n > 0 && r.d[r.n - 1] == 0) --r.n;
     return r;
 }
 

@@ -24,13 +24,13 @@ HALO_DEV Fe from_arg(const FeArg &a) {
 }
 
 // ------------------------------------------------------------------ K3: G'[j] = G[j] + xi * G[j+m]
-// xi is one scalar for the whole launch, split on the host as xi = s1 [T1] + s2 [T2] (host_math.hpp
-// glv_split): a joint double-and-add over max(|s1|, |s2|) <= 130 bits whose table
-// T1, T2, T3 = T1 + T2 is (beta^e x, +-y) -- two multiplications per point.  Every branch below
-// depends only on kernel arguments, so the 64 lanes of a wave never diverge.
+// xi is one scalar for the whole launch, expanded on the host as xi = sum_i d_i 2^i with digits from the six
+// Eisenstein units {+-1, +-lambda, +-lambda^2} (host_math.hpp glv_digits): a ~127-step double-and-add with
+// ~71 additions, each of a "free" point d_i * P = (beta^e x, +-y) -- two multiplications per input point.
+// Every branch below depends only on kernel arguments, so the 64 lanes of a wave never diverge.
 struct GlvArg {
-    uint32_t s1[5], s2[5];
-    int e0, e1, e2, neg12, nbits;
+    uint32_t dig[14];  // ten 3-bit digit codes per word, least significant digit first (host_math.hpp glv_digits)
+    int ndigits;
 };
 HALO_DEV Fq<2> fq_const(const uint32_t (&c)[9]) {
     Fq<2> r;
@@ -54,31 +54,21 @@ __global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, u
     constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
     Fq<2> x0 = hi.x, x1 = fq_mul(hi.x, fq_const(BETA)), x2 = fq_mul(hi.x, fq_const(BETA2));
     Fq<2> yp = hi.y, yn = fq_neg<2>(hi.y);
-    AffN T1, T2, T3;
-    T1.x = pick3(a.e0, x0, x1, x2);
-    T2.x = pick3(a.e1, x0, x1, x2);
-    T3.x = pick3(a.e2, x0, x1, x2);
-    T1.y = pick3(a.neg12, yp, yn, yn);
-    T2.y = T1.y;
-    T3.y = pick3(a.neg12, yn, yp, yp);
     JacN acc = jac_inf();
-    int top = a.nbits - 1;
+    int top = a.ndigits - 1;
 #pragma unroll 1
-    for (int limb = top >> 5; limb >= 0; limb--) {
-        uint32_t w1 = 0, w2 = 0;
+    for (int word = top / 10; word >= 0; word--) {
+        uint32_t w = 0;
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
-            w1 = (q == limb) ? a.s1[q] : w1;
-            w2 = (q == limb) ? a.s2[q] : w2;
-        }
+        for (int q = 0; q < 14; q++) w = (q == word) ? a.dig[q] : w;
 #pragma unroll 1
-        for (int bit = (limb == (top >> 5)) ? (top & 31) : 31; bit >= 0; bit--) {
+        for (int k = (word == top / 10) ? (top % 10) : 9; k >= 0; k--) {
             acc = jac_dbl(acc);
-            uint32_t sel = ((w1 >> bit) & 1u) | (((w2 >> bit) & 1u) << 1);
-            if (sel) {  // wave-uniform
+            uint32_t code = (w >> (3 * k)) & 7u;
+            if (code) {  // wave-uniform: +-w^e * hi = (beta^e x, +-y)
                 AffN t;
-                t.x = pick3((int)sel - 1, T1.x, T2.x, T3.x);
-                t.y = pick3((int)sel - 1, T1.y, T2.y, T3.y);
+                t.x = pick3((int)((code - 1) % 3), x0, x1, x2);
+                t.y = code > 3 ? yn : yp;
                 acc = jac_madd(acc, t);
             }
         }
@@ -338,10 +328,11 @@ __global__ __launch_bounds__(256) void k_scale(uint64_t *__restrict__ v, uint32_
 // ================================================================== host launchers
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont) {
     if (m == 0) return HALO_OK;
-    host::GlvSplit sp = host::glv_split(xi_mont);
+    host::GlvDigits dg = host::glv_digits(xi_mont);
     GlvArg a;
-    for (int i = 0; i < 5; ++i) { a.s1[i] = sp.s1[i]; a.s2[i] = sp.s2[i]; }
-    a.e0 = sp.e[0]; a.e1 = sp.e[1]; a.e2 = sp.e[2]; a.neg12 = sp.neg12; a.nbits = sp.nbits;
+    for (int i = 0; i < 14; ++i) a.dig[i] = 0;
+    for (int i = 0; i < dg.n; ++i) a.dig[i / 10] |= (uint32_t)dg.d[i] << (3 * (i % 10));
+    a.ndigits = dg.n;
     HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, a);
     HALO_HIP(hipGetLastError());
     return HALO_OK;

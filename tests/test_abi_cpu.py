@@ -92,25 +92,26 @@ def test_product_does_not_import_oracle():
                 assert "import orc" not in text and "pallas_model" not in text and "liborc" not in text and "halo_cpu" not in text, f
 
 
-def test_glv_split_host(hal):
-    """xi == s1 * (+-lambda^e0) + s2 * (+-lambda^e1) (mod r) with s1, s2 < 2^130, and the third table
-    entry is the sum of the first two (P + phi P + phi^2 P = 0): host_math.hpp glv_split."""
+def test_glv_digits_host(hal):
+    """xi == sum_i d_i 2^i (mod r) with d_i in {0, +-1, +-lambda, +-lambda^2}, at most ~131 digits, and a non-zero
+    density of about 0.6 (host_math.hpp glv_digits: the expansion the fold kernel walks)."""
     import pallas_model as pm
     lib = hal.load()
     lam = 0x6819a58283e528e511db4d81cf70f5a0fed467d47c033af2aa9d2e050aa0e4f
     assert (lam * lam + lam + 1) % pm.R_ORDER == 0
+    unit = [None, 1, lam, lam * lam % pm.R_ORDER, -1, -lam, -(lam * lam) % pm.R_ORDER]
     rng = pm.SplitMix64(4)
-    xs = [0, 1, 2, 3, pm.R_ORDER - 1, pm.R_ORDER - 2, lam, lam + 1, pm.R_ORDER - lam, (1 << 254) % pm.R_ORDER]
+    xs = [0, 1, 2, 3, pm.R_ORDER - 1, pm.R_ORDER - 2, lam, lam + 1, pm.R_ORDER - lam, (1 << 254) % pm.R_ORDER, lam * lam % pm.R_ORDER]
     xs += [rng.next_scalar() for _ in range(300)]
+    nonzero = total = 0
     for x in xs:
-        out = (C.c_uint32 * 16)()
-        assert lib.halo_test_glv_split(hal._lib.ptr(orc.fr_to_mont(x)), out) == 0
-        s1 = sum(out[i] << (32 * i) for i in range(5))
-        s2 = sum(out[5 + i] << (32 * i) for i in range(5))
-        e0, e1, e2, neg12, nbits = out[10], out[11], out[12], out[13], out[14]
-        sign = -1 if neg12 else 1
-        assert (sign * (s1 * pow(lam, e0, pm.R_ORDER) + s2 * pow(lam, e1, pm.R_ORDER)) - x) % pm.R_ORDER == 0
-        assert max(s1.bit_length(), s2.bit_length()) == nbits <= 130
-        assert sorted((e0, e1, e2)) == [0, 1, 2]
-        # T3 = T1 + T2: lambda^e0 + lambda^e1 == -lambda^e2
-        assert (pow(lam, e0, pm.R_ORDER) + pow(lam, e1, pm.R_ORDER) + pow(lam, e2, pm.R_ORDER)) % pm.R_ORDER == 0
+        out = (C.c_uint8 * 144)()
+        n = C.c_int()
+        assert lib.halo_test_glv_digits(hal._lib.ptr(orc.fr_to_mont(x)), out, C.byref(n)) == 0
+        assert 0 <= n.value <= 132 and all(0 <= out[i] <= 6 for i in range(144)) and all(out[i] == 0 for i in range(n.value, 144))
+        assert n.value == 0 or out[n.value - 1] != 0
+        assert (sum(unit[out[i]] << i for i in range(n.value) if out[i]) - x) % pm.R_ORDER == 0
+        if x > 1 << 200:
+            nonzero += sum(1 for i in range(n.value) if out[i]); total += n.value
+    assert 0.5 < nonzero / total < 0.66
+
