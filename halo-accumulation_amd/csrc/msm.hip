@@ -387,11 +387,11 @@ HALO_DEV XyzzN bucket_value(const uint32_t *__restrict__ partial, const uint32_t
 // ------------------------------------------------------------------------------ reduce
 // Lane l holds S (sum of its buckets) and T (their sum weighted 1..L relative to the lane's
 // first bucket).  Returns in lane 0: S_tot = sum_l S_l and T_tot = sum_l (T_l + l * 2^k * S_l).
-HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k) {
+HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, int live = 64) {
     int lane = threadIdx.x & 63;
-    // inclusive suffix scan: S_l <- sum_{j >= l} S_j
+    // inclusive suffix scan: S_l <- sum_{j >= l} S_j   (lanes >= live hold infinity: their steps are skipped)
 #pragma unroll 1
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int off = 1; off < live; off <<= 1) {
         XyzzN o = xyzz_shfl(S, (lane + off) & 63);
         if (lane + off < 64) xyzz_add(S, o);
     }
@@ -400,8 +400,11 @@ HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k) {
 #pragma unroll 1
     for (int i = 0; i < k; i++) V = xyzz_dbl(V);
     xyzz_add(T, V);
+    int top = 32;
+    while (top >= live && top > 1) top >>= 1;  // first offset that still pairs two live lanes
+    if (live <= 1) top = 0;
 #pragma unroll 1
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = top; off >= 1; off >>= 1) {
         XyzzN o = xyzz_shfl(T, (lane + off) & 63);
         if (lane < off) xyzz_add(T, o);
     }
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__
         S = xyzz_load(o);
         T = xyzz_load(o + XYZZ_WORDS);
     }
-    wave_weighted_sum(S, T, seg_shift);
+    wave_weighted_sum(S, T, seg_shift, (int)nseg);  // only nseg lanes hold a segment
     if (lane == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
 }
 
