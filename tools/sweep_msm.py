@@ -13,6 +13,7 @@ cs = [int(x) for x in sys.argv[2].split(",")]
 spans = [int(x) for x in sys.argv[3].split(",")]
 n = 1 << lg
 ctx = h._lib.Context(urs_n=n)
+ctx.set_task_len(int(os.environ.get('TASK_LEN', '0')))
 d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(2, n, d.data_ptr())
 ref = None
