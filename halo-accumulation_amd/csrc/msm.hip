@@ -411,7 +411,8 @@ HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, int live = 64) {
 }
 
 // one wave per (window, segment of 64*L buckets)
-__global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
+// at most 256 VGPRs: a wave of this kernel can then share a SIMD with a wave of k_msm_accumulate (256 of the 512)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_msm_reduce1(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
                                                     const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff, uint32_t B,
                                                     uint32_t L, int logL, uint32_t nseg, uint32_t *__restrict__ seg) {
     uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
