@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restric
                                                        const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t kmax,
                                                        uint32_t *__restrict__ meta, uint32_t *__restrict__ task_g) {
     __shared__ uint32_t bins[KMAX + 1];
+    if (blockIdx.x * 256 >= meta[0]) return;  // the grid covers the worst case; blocks past the last task leave at once
     if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
     __syncthreads();
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -287,8 +288,12 @@ __global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restric
 }
 __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restrict__ task_g, uint32_t *__restrict__ meta,
                                                         uint32_t *__restrict__ order) {
-    __shared__ uint32_t bins[KMAX + 1], base[KMAX + 1];
-    if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
+    __shared__ uint32_t bins[KMAX + 1], base[KMAX + 1], tot[KMAX + 1];
+    if (blockIdx.x * 256 >= meta[0]) return;
+    if (threadIdx.x <= KMAX) {
+        bins[threadIdx.x] = 0;
+        tot[threadIdx.x] = meta[2 + threadIdx.x];  // global bin totals (65 values), read once per block
+    }
     __syncthreads();
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     bool live = t < meta[0];
@@ -299,8 +304,8 @@ __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restri
     }
     __syncthreads();
     if (threadIdx.x <= KMAX) {
-        uint32_t start = 0;  // exclusive prefix of the global bin totals (65 values)
-        for (uint32_t k = 0; k < threadIdx.x; k++) start += meta[2 + k];
+        uint32_t start = 0;  // exclusive prefix of the totals
+        for (uint32_t k = 0; k < threadIdx.x; k++) start += tot[k];
         base[threadIdx.x] = start + (bins[threadIdx.x] ? atomicAdd(&meta[70 + threadIdx.x], bins[threadIdx.x]) : 0u);
     }
     __syncthreads();
