@@ -98,6 +98,7 @@ _SIGS = {
     "halo_msm_dev_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, u64p]),
     "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -313,6 +314,9 @@ class Context:
 
     def set_reduce_span(self, span):
         check(self.lib.halo_set_reduce_span(self.h, span))
+
+    def set_sort_mode(self, mode):
+        check(self.lib.halo_set_sort_mode(self.h, mode))
 
     def set_task_len(self, n):
         check(self.lib.halo_set_task_len(self.h, n))

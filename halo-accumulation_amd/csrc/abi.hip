@@ -791,6 +791,11 @@ int halo_set_reduce_span(halo_ctx *ctx, int span) {
     return HALO_OK;
 }
 
+int halo_set_sort_mode(halo_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) { set_error("sort mode must be -1 (automatic), 0 (one level) or 1 (two levels)"); return HALO_E_ARG; }
+    ctx->sort_two_level = mode;
+    return HALO_OK;
+}
 int halo_set_task_len(halo_ctx *ctx, int len) {
     if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }
     ctx->task_len = len;

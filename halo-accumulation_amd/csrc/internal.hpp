@@ -74,6 +74,7 @@ struct MsmWorkspace {
     uint32_t *d_starts = nullptr;    // W*B exclusive scan within 4096-entry blocks
     uint32_t *d_blockoff = nullptr;  // per 4096-entry block offset
     uint32_t *d_sorted = nullptr;    // n*W entries: point index | sign << 31
+    uint32_t *d_presort = nullptr;   // the same entries grouped by bucket range only (two-level sort of large MSMs)
     uint32_t *d_buckets = nullptr;   // one native XYZZ partial (40 words) per task
     uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
     uint32_t *d_task_g = nullptr, *d_order = nullptr;  // per task: bucket | length bin << 24; tasks by decreasing length
@@ -117,6 +118,7 @@ struct halo_ctx {
     halo::Profiler prof;
     int window_bits = 0;
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
+    int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^18), 0 never, 1 whenever the shape allows
     int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)

@@ -176,6 +176,166 @@ __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------ two-level sort (large MSMs)
+// k_msm_scatter writes every entry to its final place: 16.8 M isolated 4-byte stores at n = 2^20, each of
+// which costs a 32-byte HBM transaction (WRITE_SIZE 525 MB for 67 MB of payload).  For large MSMs the sort
+// is split so that every store lands next to recent ones:
+//   1. coarse: the window's buckets are cut into NC = B / 2^F ranges; block (window, chunk) appends its
+//      entries to NC runs, each advancing sequentially (the open lines stay in L2 until they are full);
+//   2. fine: block (window, range) reads its run (about n / NC entries, contiguous), counts its 2^F buckets
+//      in LDS, and places the entries inside its own region of the output (~128 KiB: L2-resident).
+// The fine pass produces the bucket counts and absolute start offsets as a by-product (no global scan).
+#ifndef HALO_FINE_BITS
+#define HALO_FINE_BITS 10
+#endif
+constexpr int FINE_BITS = HALO_FINE_BITS;
+constexpr uint32_t NC_MAX = 32768u >> FINE_BITS;  // bucket ranges per window at c = 16
+
+// coarse histogram: chist[(w * nchunks + chunk) * NC + c]; one private row of counters per wave
+__global__ __launch_bounds__(1024) void k_msm_coarse_hist(const uint16_t *__restrict__ digits, uint32_t n, uint32_t NC, uint32_t nchunks,
+                                                          uint32_t chunk_len, uint32_t *__restrict__ chist) {
+    __shared__ uint32_t cnt[16 * NC_MAX];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    for (uint32_t k = threadIdx.x; k < 16 * NC_MAX; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    uint32_t *mine = cnt + NC_MAX * (threadIdx.x >> 6);
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *dg = digits + (size_t)w * n;
+    for (uint32_t i = lo + 8 * threadIdx.x; i < hi; i += 8 * 1024) {  // n and chunk_len are multiples of 8
+        uint4 q = *reinterpret_cast<const uint4 *>(dg + i);
+        uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t d = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            if (d != DIGIT_NONE) atomicAdd(&mine[(d & 0x7FFFu) >> FINE_BITS], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        uint32_t t = 0;
+        for (int r = 0; r < 16; r++) t += cnt[NC_MAX * r + threadIdx.x];
+        chist[((size_t)w * nchunks + chunk) * NC + threadIdx.x] = t;
+    }
+}
+// one block: chist <- exclusive prefix over the chunks of each (window, range); cstart[p] = start of run p = w * NC + c
+// in the presorted array, cstart[P] = number of entries.  P <= 4096.
+__global__ __launch_bounds__(1024) void k_msm_coarse_scan(uint32_t *__restrict__ chist, uint32_t P, uint32_t NC, uint32_t nchunks,
+                                                          uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t part[1024];
+    uint32_t tot[4];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t p = threadIdx.x * 4 + k, run = 0;
+        if (p < P) {
+            uint32_t w = p / NC, c = p % NC;
+            for (uint32_t ch = 0; ch < nchunks; ch++) {
+                uint32_t *q = chist + ((size_t)w * nchunks + ch) * NC + c;
+                uint32_t t = *q;
+                *q = run;
+                run += t;
+            }
+        }
+        tot[k] = sum;
+        sum += run;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (uint32_t)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t excl = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (threadIdx.x * 4 + k < P) cstart[threadIdx.x * 4 + k] = excl + tot[k];
+    if (threadIdx.x == 1023) cstart[P] = part[1023];
+}
+// coarse scatter: presort[run position] = i | sign << 31 (plain index; the member's base offset is added by the fine pass)
+__global__ __launch_bounds__(1024) void k_msm_coarse_scatter(const uint16_t *__restrict__ digits, uint32_t n, uint32_t NC, uint32_t nchunks,
+                                                             uint32_t chunk_len, const uint32_t *__restrict__ chist,
+                                                             const uint32_t *__restrict__ cstart, int packed, uint32_t *__restrict__ presort) {
+    __shared__ uint32_t cur[NC_MAX];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    if (threadIdx.x < NC) cur[threadIdx.x] = cstart[w * NC + threadIdx.x] + chist[((size_t)w * nchunks + chunk) * NC + threadIdx.x];
+    __syncthreads();
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint16_t *dg = digits + (size_t)w * n;
+    for (uint32_t i = lo + 8 * threadIdx.x; i < hi; i += 8 * 1024) {
+        uint4 q = *reinterpret_cast<const uint4 *>(dg + i);
+        uint32_t v[4] = {q.x, q.y, q.z, q.w};
+        uint32_t pos[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t d = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            pos[k] = d != DIGIT_NONE ? atomicAdd(&cur[(d & 0x7FFFu) >> FINE_BITS], 1u) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t d = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            // packed (n <= 2^21): the bucket's low bits ride along in bits 21..30, the fine pass needs no digit lookup
+            if (pos[k] != 0xFFFFFFFFu) presort[pos[k]] = (i + k) | ((d >> 15) << 31) | (packed ? (d & ((1u << FINE_BITS) - 1u)) << 21 : 0u);
+        }
+    }
+}
+// fine sort of run p = (window, range): counts / absolute starts of its 2^F buckets, entries placed in [lo, hi) of `sorted`
+template <bool PACKED>
+__global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ digits, uint32_t n,
+                                                        uint32_t B, uint32_t NC, const uint32_t *__restrict__ cstart, uint32_t W_member,
+                                                        MemberOffsets offs, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
+                                                        uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t hist[1 << FINE_BITS], scan[1 << FINE_BITS];
+    constexpr uint32_t FMASK = (1u << FINE_BITS) - 1u, IMASK = PACKED ? 0x1FFFFFu : 0x7FFFFFFFu;
+    uint32_t p = blockIdx.x, w = p / NC, c = p % NC;
+    uint32_t lo = cstart[p], hi = cstart[p + 1];
+    uint32_t off = offs.v[w / W_member];
+    const uint16_t *dg = digits + (size_t)w * n;
+    auto fine_of = [&](uint32_t v) -> uint32_t { return PACKED ? (v >> 21) & FMASK : (uint32_t)dg[v & IMASK] & FMASK; };
+    constexpr uint32_t NB = 1u << FINE_BITS;  // buckets of this block (<= 1024 threads: one bucket per thread at most)
+    bool owner = threadIdx.x < NB;
+    if (owner) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {  // four independent entries per lane per trip
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = e + k * 1024 < hi ? presort[e + k * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e + k * 1024 < hi) atomicAdd(&hist[fine_of(v[k])], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = owner ? hist[threadIdx.x] : 0u;
+    if (owner) scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < NB; o <<= 1) {
+        uint32_t t = (owner && threadIdx.x >= o) ? scan[threadIdx.x - o] : 0u;
+        __syncthreads();
+        if (owner) scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (owner) {
+        uint32_t begin = lo + scan[threadIdx.x] - mine;
+        uint32_t g = w * B + (c << FINE_BITS) + threadIdx.x;
+        counts[g] = mine;
+        starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the launcher
+        hist[threadIdx.x] = begin;  // now the bucket's write cursor
+    }
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
+        uint32_t v[4], pos[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = e + k * 1024 < hi ? presort[e + k * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pos[k] = e + k * 1024 < hi ? atomicAdd(&hist[fine_of(v[k])], 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e + k * 1024 < hi) sorted[pos[k]] = ((v[k] & IMASK) + off) | (v[k] & 0x80000000u);
+    }
+}
+
 // ------------------------------------------------------------------------------ scan
 // 4096 entries per block: local exclusive scan + block total.
 __global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t total, uint32_t *__restrict__ out,
@@ -683,7 +843,7 @@ struct WorkspaceNeed {
 };
 static void workspace_release(MsmWorkspace &ws) {
     uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
-    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_ntask, ws.d_toff,
+    uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_presort, ws.d_ntask, ws.d_toff,
                        ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
     for (auto p : p64) (void)hipFree(p);
     for (auto p : p32) (void)hipFree(p);
@@ -707,6 +867,7 @@ static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
     HALO_HIP(hipMalloc(&ws.d_starts, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_blockoff, 1024 * 4));
     HALO_HIP(hipMalloc(&ws.d_sorted, ws.cap_sorted * 4));
+    HALO_HIP(hipMalloc(&ws.d_presort, ws.cap_sorted * 4));  // coarse runs of the two-level sort
     HALO_HIP(hipMalloc(&ws.d_buckets, ws.cap_tasks * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_ntask, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_toff, ws.cap_counts * 4));
@@ -821,7 +982,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len;
+    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     if (graphs && ws.graph_exec && key == ws.graph_key) {
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
@@ -886,14 +1047,35 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     if (vec) chunk_len = (chunk_len + 7) / 8 * 8;
     dim3 gridh((unsigned)(Wt * nchunks)), b1024(1024);
     size_t lds_bytes = (size_t)p.B * 4;
-    HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);
-    HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
-                ws.d_counts);
     uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
-    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
-    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
-    HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
-                ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
+    // large MSMs: two-level sort (coarse runs, then a fine sort per run) -- every store lands next to recent ones
+    uint32_t NC = p.B >> FINE_BITS;
+    bool two_level = vec && p.B >= (1u << FINE_BITS) && (size_t)Wt * NC <= 4096 && ws.d_presort &&
+                     (ctx->sort_two_level > 0 || (ctx->sort_two_level < 0 && n >= ((size_t)1 << 18)));
+    if (two_level) {
+        uint32_t P = Wt * NC;
+        uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + 16384;  // Wt * nchunks * NC <= 8192 and P + 1 <= 4097 words
+        HALO_LAUNCH(ctx, "k_msm_coarse_hist", k_msm_coarse_hist, gridh, b1024, 0, d_digits, (uint32_t)n, NC, nchunks, chunk_len, chist);
+        HALO_LAUNCH(ctx, "k_msm_coarse_scan", k_msm_coarse_scan, dim3(1), b1024, 0, chist, P, NC, nchunks, cstart);
+        int packed = n <= ((size_t)1 << 21) ? 1 : 0;  // index (21 bits) + fine bucket bits (10) + sign fit one word
+        HALO_LAUNCH(ctx, "k_msm_coarse_scatter", k_msm_coarse_scatter, gridh, b1024, 0, d_digits, (uint32_t)n, NC, nchunks, chunk_len, chist, cstart,
+                    packed, ws.d_presort);
+        HALO_HIP(hipMemsetAsync(ws.d_blockoff, 0, 1024 * 4, s));  // the fine pass writes absolute starts
+        if (packed)
+            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, 0, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
+                        offs, ws.d_counts, ws.d_starts, ws.d_sorted);
+        else
+            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<false>, dim3(P), b1024, 0, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
+                        offs, ws.d_counts, ws.d_starts, ws.d_sorted);
+    } else {
+        HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);
+        HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
+                    ws.d_counts);
+        HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
+        HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
+        HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
+                    ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
+    }
     dim3 gridb((unsigned)((total + 255) / 256));
     HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
     // chain bound per lane: 64 where the launch is throughput-bound, 16 where it is latency-bound

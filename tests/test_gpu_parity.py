@@ -194,6 +194,29 @@ def test_msm_tuning_knobs_do_not_change_results(hal, ctx16k, urs4096, span, task
         ctx16k.set_reduce_span(3)
 
 
+@pytest.mark.parametrize("n,c", [(4096, 11), (4096, 13), (16384, 16), (1000, 13), (16384, 12)])
+def test_msm_two_level_sort_equals_one_level(hal, ctx16k, urs4096, n, c):
+    """halo_set_sort_mode: the coarse-runs + fine-sort path (automatic from n = 2^18) forced at small sizes, against the
+    oracle / the one-pass sort; a fat bucket and a zero stretch included (n = 1000 is not a multiple of 8: falls back)."""
+    sc, _ = orc.rng_scalars(777 + n + c, n)
+    sc[100:600] = sc[3]
+    sc[600:700] = 0
+    ctx16k.set_window_bits(c)
+    try:
+        ctx16k.set_sort_mode(0)
+        one = ctx16k.msm(sc).tolist()
+        ctx16k.set_sort_mode(1)
+        two = ctx16k.msm(sc).tolist()
+        two_again = ctx16k.msm(sc).tolist()
+    finally:
+        ctx16k.set_sort_mode(-1); ctx16k.set_window_bits(0)
+    assert one == two == two_again
+    if n <= 4096:
+        assert one == orc.msm_affine(urs4096[:n], sc).tolist()
+    with pytest.raises(hal.HaloError):
+        ctx16k.set_sort_mode(2)
+
+
 def test_msm_degenerate_inputs(ctx16k):
     n = 4096
     gs = ctx16k.read_bases(0, n)

@@ -14,6 +14,7 @@ spans = [int(x) for x in sys.argv[3].split(",")]
 n = 1 << lg
 ctx = h._lib.Context(urs_n=n)
 ctx.set_task_len(int(os.environ.get('TASK_LEN', '0')))
+ctx.set_sort_mode(int(os.environ.get('SORT_MODE', '-1')))
 d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(2, n, d.data_ptr())
 ref = None
