@@ -118,7 +118,7 @@ struct halo_ctx {
     halo::Profiler prof;
     int window_bits = 0;
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
-    int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^18), 0 never, 1 whenever the shape allows
+    int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^17), 0 never, 1 whenever the shape allows
     int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)

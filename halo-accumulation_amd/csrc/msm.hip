@@ -191,6 +191,7 @@ __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict
 #endif
 constexpr int FINE_BITS = HALO_FINE_BITS;
 constexpr uint32_t NC_MAX = 32768u >> FINE_BITS;  // bucket ranges per window at c = 16
+constexpr uint32_t FINE_STAGE = 37888;             // entries staged in LDS by the fine pass: 148 KiB of the CU's 160 KiB
 
 // coarse histogram: chist[(w * nchunks + chunk) * NC + c]; one private row of counters per wave
 __global__ __launch_bounds__(1024) void k_msm_coarse_hist(const uint16_t *__restrict__ digits, uint32_t n, uint32_t NC, uint32_t nchunks,
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
         hist[threadIdx.x] = begin;  // now the bucket's write cursor
     }
     __syncthreads();
+    extern __shared__ uint32_t stage[];  // FINE_STAGE entries: the block's whole output region when it fits
+    bool staged = hi - lo <= FINE_STAGE;
     for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
         uint32_t v[4], pos[4];
 #pragma unroll
@@ -332,7 +335,15 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
         for (int k = 0; k < 4; k++) pos[k] = e + k * 1024 < hi ? atomicAdd(&hist[fine_of(v[k])], 1u) : 0u;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (e + k * 1024 < hi) sorted[pos[k]] = ((v[k] & IMASK) + off) | (v[k] & 0x80000000u);
+            if (e + k * 1024 < hi) {
+                uint32_t out = ((v[k] & IMASK) + off) | (v[k] & 0x80000000u);
+                if (staged) stage[pos[k] - lo] = out;  // random within LDS ...
+                else sorted[pos[k]] = out;             // a run longer than the staging area (skewed scalars): placed directly
+            }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += 1024) sorted[e] = stage[e - lo];  // ... sequential to HBM
     }
 }
 
@@ -861,6 +872,8 @@ static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
     // the LDS histograms need up to 128 KiB of dynamic LDS per block (160 KiB per CU on gfx950)
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
     HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
     HALO_HIP(hipMalloc(&ws.d_hist, ws.cap_hist * 4));          // [w][chunk][b]
     HALO_HIP(hipMalloc(&ws.d_counts, ws.cap_counts * 4));
@@ -1051,7 +1064,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     // large MSMs: two-level sort (coarse runs, then a fine sort per run) -- every store lands next to recent ones
     uint32_t NC = p.B >> FINE_BITS;
     bool two_level = vec && p.B >= (1u << FINE_BITS) && (size_t)Wt * NC <= 4096 && ws.d_presort &&
-                     (ctx->sort_two_level > 0 || (ctx->sort_two_level < 0 && n >= ((size_t)1 << 18)));
+                     (ctx->sort_two_level > 0 || (ctx->sort_two_level < 0 && n >= ((size_t)1 << 17)));
     if (two_level) {
         uint32_t P = Wt * NC;
         uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + 16384;  // Wt * nchunks * NC <= 8192 and P + 1 <= 4097 words
@@ -1062,10 +1075,10 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
                     packed, ws.d_presort);
         HALO_HIP(hipMemsetAsync(ws.d_blockoff, 0, 1024 * 4, s));  // the fine pass writes absolute starts
         if (packed)
-            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, 0, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
+            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
                         offs, ws.d_counts, ws.d_starts, ws.d_sorted);
         else
-            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<false>, dim3(P), b1024, 0, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
+            HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<false>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
                         offs, ws.d_counts, ws.d_starts, ws.d_sorted);
     } else {
         HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);

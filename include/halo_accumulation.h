@@ -206,7 +206,7 @@ int halo_set_window_bits(halo_ctx *ctx, int c);
 /* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */
 int halo_set_reduce_span(halo_ctx *ctx, int span);
 /* MSM tuning: bucket sort in one pass (0), in two (coarse runs, then a fine sort per run: 1, where the shape allows),
- * or chosen by size (-1, default: two levels from n = 2^18) */
+ * or chosen by size (-1, default: two levels from n = 2^17) */
 int halo_set_sort_mode(halo_ctx *ctx, int mode);
 /* MSM tuning: longest chain of mixed additions one lane runs in the bucket kernel (0 = automatic; 8, 16, 32, 64) */
 int halo_set_task_len(halo_ctx *ctx, int len);
