@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--depth", type=int, default=4, help="launch sequences in flight (1..4)")
-    ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one GPU, 4 on several)")
+    ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one or two GPUs, 4 on more)")
     ap.add_argument("--shard", choices=["window", "index"], default="window",
                     help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index")
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
@@ -64,7 +64,7 @@ def main():
     from halo_accumulation_amd.sharded import ShardedMsm, shard_range
 
     n = 1 << args.log_n
-    batch = args.batch if args.batch > 0 else (1 if world == 1 else 4)
+    batch = args.batch if args.batch > 0 else (1 if world <= 2 else 4)  # measured optimum per rank (tools/sweep_batch.py)
     window_mode = world > 1 and args.shard == "window"
     if window_mode:
         # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes

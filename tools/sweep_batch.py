@@ -15,6 +15,7 @@ for i in range(8):
     ctx.rng_scalars_dev(2 + i, n, d.data_ptr())
     ds.append(d)
 ref = [ctx.msm_dev(d.data_ptr(), n).tolist() for d in ds]
+parts = int(os.environ.get('PARTS', '1'))  # window shard parts - 1 of `parts` (what the last rank of a window-sharded MSM does)
 for depth, batch in combos:
     ptrs = [d.data_ptr() for d in ds[:batch]]
     def run(K):
@@ -22,7 +23,7 @@ for depth, batch in combos:
         for i in range(K):
             if len(pend) == depth:
                 o = ctx.msm_dev_batch_end(pend.pop(0), batch)
-            ctx.msm_dev_batch_begin(i % depth, ptrs, n)
+            ctx.msm_dev_batch_begin(i % depth, ptrs, n, part=parts - 1, parts=parts)
             pend.append(i % depth)
         while pend:
             o = ctx.msm_dev_batch_end(pend.pop(0), batch)
@@ -33,4 +34,4 @@ for depth, batch in combos:
     t = time.time()
     o = run(K)
     dt = (time.time() - t) / (K * batch) * 1e3
-    print("lg=%d depth=%d batch=%d  %.3f ms per MSM  (%.0f MSM/s)  same=%s" % (lg, depth, batch, dt, 1e3 / dt, o.tolist() == ref[:batch]), flush=True)
+    print("lg=%d parts=%d depth=%d batch=%d  %.3f ms per MSM share  (%.0f/s)%s" % (lg, parts, depth, batch, dt, 1e3 / dt, "  same=%s" % (o.tolist() == ref[:batch]) if parts == 1 else ""), flush=True)
