@@ -403,6 +403,44 @@ def test_msm_window_shards_2_20(hal, ctx1m):
         assert hal.point_sum(np.stack(partials)).tolist() == want
 
 
+def test_msm_randomised_configurations(hal, ctx16k, urs4096):
+    """Seeded sweep over sizes (incl. non-multiples of 8 and chunk-boundary sizes), window bits, sort modes, batch sizes,
+    window shards and scalar shapes (zeros, repeats, tiny values): every combination equals the oracle."""
+    import torch
+    rnd = np.random.RandomState(20260101)
+    sizes = [1, 7, 8, 9, 255, 256, 1023, 1024, 1025, 2040, 2048, 3333, 4088, 4096]
+    try:
+        for trial in range(36):
+            n = int(sizes[rnd.randint(len(sizes))])
+            c = int(rnd.choice([0, 8, 10, 11, 13, 14, 16]))
+            mode = int(rnd.randint(0, 2))
+            batch = int(rnd.randint(1, 5))
+            parts = int(rnd.choice([1, 1, 2, 3, 5]))
+            scs = []
+            for b in range(batch):
+                sc = orc.rng_scalars(31337 + 97 * trial + b, n)[0]
+                shape = rnd.randint(4)
+                if shape == 1:
+                    sc[rnd.rand(n) < 0.5] = 0
+                elif shape == 2:
+                    sc[:] = sc[rnd.randint(0, n, size=n) % max(1, n // 16)]  # few distinct values
+                elif shape == 3:
+                    sc[: n // 2] = orc.scalars_to_mont([int(v) for v in rnd.randint(0, 70000, size=3)] * (n // 6 + 1))[: n // 2]
+                scs.append(np.ascontiguousarray(sc))
+            want = [orc.msm_affine(urs4096[:n], sc).tolist() for sc in scs]
+            ds = [torch.from_numpy(sc.view(np.int64)).cuda() for sc in scs]
+            ctx16k.set_window_bits(c); ctx16k.set_sort_mode(mode)
+            got = []
+            for part in range(parts):
+                ctx16k.msm_dev_batch_begin(trial % 4, [d.data_ptr() for d in ds], n, part=part, parts=parts)
+                got.append(ctx16k.msm_dev_batch_end(trial % 4, batch))
+            for b in range(batch):
+                total = hal.point_sum(np.stack([g[b] for g in got]))
+                assert total.tolist() == want[b], (trial, n, c, mode, batch, parts, b)
+    finally:
+        ctx16k.set_window_bits(0); ctx16k.set_sort_mode(-1)
+
+
 def test_msm_batch_2_18_and_misuse(hal, ctx1m):
     import torch
     n = 1 << 18
