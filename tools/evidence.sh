@@ -20,6 +20,7 @@ export HALO_BENCH_BACKEND=gloo
 for N in 2 4; do
   step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 > $OUT/bench_gloo$N.json 2> $OUT/bench_gloo$N.err || exit 1
 done
+step gloo2_index; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 64 --warmup 8 --shard index > $OUT/bench_gloo2_index.json 2> $OUT/bench_gloo2_index.err || exit 1
 unset HALO_BENCH_BACKEND
 step asdl64;  timeout -k 10 600 python tools/time_acc.py 20 64 > $OUT/asdl64.json 2> $OUT/asdl64.err || exit 1
 # keep only the summaries (traces are large)
