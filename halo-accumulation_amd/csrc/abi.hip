@@ -63,6 +63,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipSetDevice(device));
     ctx->device = device;
     ctx->n = n;
+    alloc_epoch_bump();  // device memory is about to be allocated: graphs instantiated before are not replayed (msm.hip)
     for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
     ctx->stream = ctx->streams[0];
     HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 128));
@@ -72,6 +73,8 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 16 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
+    if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;          // debugging aids
+    if (const char *e = getenv("HALO_SORT_MODE")) ctx->sort_two_level = atoi(e);
     return msm_workspace_alloc(ctx, n, 0);
 }
 
@@ -125,6 +128,7 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
     if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
     st->ctx = ctx;
     st->n = st->m = n;
+    alloc_epoch_bump();
     int rc = HALO_OK;
     if (hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) { delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
     do {
@@ -214,6 +218,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     ctx->prof.collect();
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     msm_workspace_free(ctx);
+    alloc_epoch_bump();
     (void)hipFree(ctx->d_bases);
     (void)hipFree(ctx->d_tmp_a);
     (void)hipFree(ctx->d_tmp_b);
@@ -633,6 +638,7 @@ int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4
 
 void halo_ipa_destroy(halo_ipa *st) {
     if (!st) return;
+    alloc_epoch_bump();
     if (st->ctx) {
         (void)hipSetDevice(st->ctx->device);
         (void)hipStreamSynchronize(st->ctx->stream);

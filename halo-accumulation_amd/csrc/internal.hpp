@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -39,12 +41,14 @@ struct Profiler {
     void collect();  // needs the stream to be idle
 };
 
+inline bool debug_trace() { static const bool on = getenv("HALO_TRACE") != nullptr; return on; }
 inline bool prof_is_dominant(const char *name) { return name[2] == 'm' ? name[6] == 'a' : (name[2] == 'f' && name[7] == 'p'); }
 // Launch wrapper: brackets the launch with events when profiling is on.
 #define HALO_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
     do {                                                                                     \
         bool _p = (ctx)->prof.on && (!(ctx)->prof.dominant_only || halo::prof_is_dominant(name)); \
         if (_p) (ctx)->prof.begin(name, (ctx)->stream);                                      \
+        if (halo::debug_trace()) fprintf(stderr, "[halo] launch %s ctx=%p stream=%p\n", name, (void *)(ctx), (void *)(ctx)->stream); \
         hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);          \
         if (_p) (ctx)->prof.end((ctx)->stream);                                              \
     } while (0)
@@ -101,6 +105,7 @@ struct MsmWorkspace {
     };
     GraphKey seen_key, graph_key;
     hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_epoch = 0;  // alloc_epoch() when graph_exec was instantiated
     MsmPlan graph_plan{};
 };
 
@@ -148,6 +153,9 @@ struct halo_ipa {
 namespace halo {
 
 // ---- msm.hip
+// counts the (de)allocations of device memory by this library (all contexts of the process)
+uint64_t alloc_epoch();
+void alloc_epoch_bump();
 int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);
 void msm_workspace_free(halo_ctx *ctx);
 // asynchronous halves of msm_run on workspace/stream `slot`

@@ -18,6 +18,7 @@
 //                     core and a > 1 ms serial chain for one GPU lane)
 // msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
 // overlap on the context's slots (workspace + stream each).
+#include <atomic>
 #include <thread>
 
 #include "curve.cuh"
@@ -852,7 +853,13 @@ static size_t max_counts() { return (size_t)16 * 32768; }  // c = 16 is the larg
 struct WorkspaceNeed {
     size_t n, counts, sorted, tasks, hist, windows;
 };
+static std::atomic<uint64_t> g_alloc_epoch{0};
+uint64_t alloc_epoch() { return g_alloc_epoch.load(std::memory_order_relaxed); }
+void alloc_epoch_bump() { g_alloc_epoch.fetch_add(1, std::memory_order_relaxed); }
+
 static void workspace_release(MsmWorkspace &ws) {
+    alloc_epoch_bump();
+    if (debug_trace()) fprintf(stderr, "[halo] workspace release %p (graph %p)\n", (void *)&ws, (void *)ws.graph_exec);
     uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
     uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_presort, ws.d_ntask, ws.d_toff,
                        ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
@@ -863,6 +870,7 @@ static void workspace_release(MsmWorkspace &ws) {
     ws = MsmWorkspace();
 }
 static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
+    alloc_epoch_bump();
     ws.cap_n = need.n;
     ws.cap_counts = need.counts;
     ws.cap_sorted = need.sorted;
@@ -997,7 +1005,17 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     MsmWorkspace::GraphKey key;
     key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
-    if (graphs && ws.graph_exec && key == ws.graph_key) {
+    // A graph is kept only while the same key keeps arriving on this slot (the bench loop, the rounds of an open)
+    // and while no device memory of this library has been allocated or freed since it was instantiated: replaying
+    // an old graph after another context had re-allocated its workspaces ended in a GPU memory fault on ROCm 7.2
+    // (tests/test_gpu_parity.py: pipelined slots -> randomised configurations -> the same scalars again).
+    if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != alloc_epoch())) {
+        (void)hipGraphExecDestroy(ws.graph_exec);
+        ws.graph_exec = nullptr;
+        ws.graph_key = MsmWorkspace::GraphKey();
+    }
+    if (graphs && ws.graph_exec) {
+        if (debug_trace()) fprintf(stderr, "[halo] graph REPLAY ctx=%p slot=%d n=%zu\n", (void *)ctx, slot, n);
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
         ws.plan = ws.graph_plan;
         ws.in_flight = true;
@@ -1005,6 +1023,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     }
     bool capture = graphs && key == ws.seen_key;
     ws.seen_key = key;
+    if (debug_trace()) fprintf(stderr, "[halo] msm enqueue ctx=%p slot=%d n=%zu batch=%d part=%d/%d capture=%d\n", (void *)ctx, slot, n, members.count, members.part, members.parts, (int)capture);
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
     int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n);
     if (capture) {
@@ -1018,6 +1037,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         if (e != hipSuccess) { ws.graph_exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
         ws.graph_key = key;
         ws.graph_plan = ws.plan;
+        ws.graph_epoch = alloc_epoch();
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
     }
     if (rc) return rc;
