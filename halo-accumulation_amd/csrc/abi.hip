@@ -73,8 +73,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 16 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
-    if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;          // debugging aids
-    if (const char *e = getenv("HALO_SORT_MODE")) ctx->sort_two_level = atoi(e);
+    if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;  // HALO_GRAPHS=0: never replay launch graphs
     return msm_workspace_alloc(ctx, n, 0);
 }
 

@@ -564,8 +564,19 @@ HALO_DEV XyzzN bucket_value(const uint32_t *__restrict__ partial, const uint32_t
 // ------------------------------------------------------------------------------ reduce
 // Lane l holds S (sum of its buckets) and T (their sum weighted 1..L relative to the lane's
 // first bucket).  Returns in lane 0: S_tot = sum_l S_l and T_tot = sum_l (T_l + l * 2^k * S_l).
-HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, int live = 64) {
+// `park` (36 words per lane, LDS) holds T while S is scanned: with S, T, a shuffled copy and the temporaries of an
+// addition live together the kernel needed 258 VGPRs, i.e. one wave per SIMD and no room next to a 256-register
+// wave of k_msm_accumulate; forcing 256 made it spill (and a kernel with scratch inside a replayed hipGraph is
+// what faulted on ROCm 7.2 once the queue's scratch had been re-assigned).
+HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, uint32_t *park, int live = 64) {
     int lane = threadIdx.x & 63;
+    {
+        uint32_t *mine = park + lane;  // word j of lane l at park[64 * j + l]: conflict-free
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            mine[64 * j] = T.x.v[j]; mine[64 * (9 + j)] = T.y.v[j]; mine[64 * (18 + j)] = T.zz.v[j]; mine[64 * (27 + j)] = T.zzz.v[j];
+        }
+    }
     // inclusive suffix scan: S_l <- sum_{j >= l} S_j   (lanes >= live hold infinity: their steps are skipped)
 #pragma unroll 1
     for (int off = 1; off < live; off <<= 1) {
@@ -576,6 +587,13 @@ HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, int live = 64) {
     XyzzN V = (lane >= 1) ? S : xyzz_inf();
 #pragma unroll 1
     for (int i = 0; i < k; i++) V = xyzz_dbl(V);
+    {
+        const uint32_t *mine = park + lane;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            T.x.v[j] = mine[64 * j]; T.y.v[j] = mine[64 * (9 + j)]; T.zz.v[j] = mine[64 * (18 + j)]; T.zzz.v[j] = mine[64 * (27 + j)];
+        }
+    }
     xyzz_add(T, V);
     int top = 32;
     while (top >= live && top > 1) top >>= 1;  // first offset that still pairs two live lanes
@@ -588,10 +606,11 @@ HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, int live = 64) {
 }
 
 // one wave per (window, segment of 64*L buckets)
-// at most 256 VGPRs: a wave of this kernel can then share a SIMD with a wave of k_msm_accumulate (256 of the 512)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_msm_reduce1(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
+// at most 256 VGPRs (see wave_weighted_sum): a wave of this kernel can share a SIMD with a wave of k_msm_accumulate
+__global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
                                                     const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff, uint32_t B,
                                                     uint32_t L, int logL, uint32_t nseg, uint32_t *__restrict__ seg) {
+    __shared__ uint32_t park[36 * 64];
     uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
     uint32_t lane = threadIdx.x;
     uint32_t first = s * 64 * L + lane * L;
@@ -604,7 +623,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         xyzz_add(run, b);
         xyzz_add(tot, run);
     }
-    wave_weighted_sum(run, tot, logL);
+    wave_weighted_sum(run, tot, logL, park);
     if (lane == 0) {
         uint32_t *o = seg + 2 * XYZZ_WORDS * ((size_t)w * nseg + s);
         xyzz_store(o, run);
@@ -614,6 +633,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 // one wave per window over its nseg <= 64 segments; segment stride = 64*L buckets = 2^seg_shift
 __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__ seg, uint32_t nseg, int seg_shift,
                                                     uint64_t *__restrict__ winsum) {
+    __shared__ uint32_t park[36 * 64];
     uint32_t w = blockIdx.x, lane = threadIdx.x;
     XyzzN S = xyzz_inf(), T = xyzz_inf();
     if (lane < nseg) {
@@ -621,7 +641,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__
         S = xyzz_load(o);
         T = xyzz_load(o + XYZZ_WORDS);
     }
-    wave_weighted_sum(S, T, seg_shift, (int)nseg);  // only nseg lanes hold a segment
+    wave_weighted_sum(S, T, seg_shift, park, (int)nseg);  // only nseg lanes hold a segment
     if (lane == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
 }
 
@@ -1007,14 +1027,16 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     // A graph is kept only while the same key keeps arriving on this slot (the bench loop, the rounds of an open)
     // and while no device memory of this library has been allocated or freed since it was instantiated: replaying
-    // an old graph after another context had re-allocated its workspaces ended in a GPU memory fault on ROCm 7.2
-    // (tests/test_gpu_parity.py: pipelined slots -> randomised configurations -> the same scalars again).
+    // an old graph after other work -- another context re-allocating its workspaces, the caller freeing the scalar
+    // buffer and getting the same address back for a new one -- ended in a GPU memory fault on ROCm 7.2
+    // (tests/test_gpu_parity.py: pipelined slots -> randomised configurations -> batch_2_18, in that order).
+    // Callers must keep the scalar buffers of a repeated launch allocated between the repetitions.
     if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != alloc_epoch())) {
         (void)hipGraphExecDestroy(ws.graph_exec);
         ws.graph_exec = nullptr;
         ws.graph_key = MsmWorkspace::GraphKey();
     }
-    if (graphs && ws.graph_exec) {
+    if (graphs && ws.graph_exec && key == ws.graph_key) {
         if (debug_trace()) fprintf(stderr, "[halo] graph REPLAY ctx=%p slot=%d n=%zu\n", (void *)ctx, slot, n);
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
         ws.plan = ws.graph_plan;
