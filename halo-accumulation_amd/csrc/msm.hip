@@ -9,7 +9,7 @@
 //   k_msm_hist        per (window, chunk) histogram with all 2^(c-1) counters in LDS
 //   k_msm_colsum      bucket sizes + per-chunk prefixes; k_scan_*: exclusive scan of the sizes
 //   k_msm_scatter     point indices grouped by bucket (LDS cursors)
-//   k_msm_ntasks/_task_meta/_task_bins/_task_order
+//   k_msm_task_bins/_task_order
 //                     buckets cut into tasks of <= kmax entries, tasks sorted by decreasing length
 //   k_msm_accumulate  one lane per task: XYZZ mixed adds over its index list (dominant kernel)
 //   k_msm_combine_*   partials of multi-task buckets folded into the bucket value
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(1024) void k_msm_hist(const uint16_t *__restrict__ 
     for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = lds[b];
 }
 // per bucket: total over chunks -> counts[g]; hist[w][chunk][b] <- exclusive prefix over chunks
-__global__ __launch_bounds__(256) void k_msm_colsum(uint32_t *__restrict__ hist, uint32_t B, uint32_t nchunks, uint32_t total,
-                                                    uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void k_msm_colsum(uint32_t *__restrict__ hist, uint32_t B, uint32_t nchunks, uint32_t total, uint32_t kmax,
+                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ ntask) {
     uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     uint32_t w = g / B, b = g % B;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void k_msm_colsum(uint32_t *__restrict__ hist,
         run += t;
     }
     counts[g] = run;
+    ntask[g] = (run + kmax - 1) / kmax;  // tasks of at most kmax entries (see the accumulate section)
 }
 struct MemberOffsets { uint32_t v[MSM_MAX_BATCH]; };
 __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t nchunks,
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(1024) void k_msm_coarse_scatter(const uint16_t *__r
 template <bool PACKED>
 __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ digits, uint32_t n,
                                                         uint32_t B, uint32_t NC, const uint32_t *__restrict__ cstart, uint32_t W_member,
-                                                        MemberOffsets offs, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
-                                                        uint32_t *__restrict__ sorted) {
+                                                        MemberOffsets offs, uint32_t kmax, uint32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ sorted) {
     __shared__ uint32_t hist[1 << FINE_BITS], scan[1 << FINE_BITS];
     constexpr uint32_t FMASK = (1u << FINE_BITS) - 1u, IMASK = PACKED ? 0x1FFFFFu : 0x7FFFFFFFu;
     uint32_t p = blockIdx.x, w = p / NC, c = p % NC;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
         uint32_t begin = lo + scan[threadIdx.x] - mine;
         uint32_t g = w * B + (c << FINE_BITS) + threadIdx.x;
         counts[g] = mine;
+        ntask[g] = (mine + kmax - 1) / kmax;
         starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the launcher
         hist[threadIdx.x] = begin;  // now the bucket's write cursor
     }
@@ -396,31 +398,11 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *blocksum, uint32_t 
 // than KMAX mixed adds, whatever the scalar distribution (all-equal scalars, or a top window
 // with two real bits, put n/4 .. n points into one bucket).  ntask[g] = ceil(count/KMAX);
 // toff = exclusive scan of ntask.  One lane per task; a bucket's value is the partial of its
-// first task once k_msm_combine_big has folded the partials of multi-task buckets into it.
+// first task once k_msm_combine has folded the partials of multi-task buckets into it.
 constexpr uint32_t KMAX = 64;  // largest task length (plan.kmax <= KMAX)
-
-__global__ __launch_bounds__(256) void k_msm_ntasks(const uint32_t *__restrict__ counts, uint32_t total, uint32_t kmax,
-                                                    uint32_t *__restrict__ ntask) {
-    uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    ntask[g] = (counts[g] + kmax - 1) / kmax;
-}
 
 HALO_DEV uint32_t scan_at(const uint32_t *__restrict__ in_block, const uint32_t *__restrict__ blockoff, uint32_t g) {
     return in_block[g] + blockoff[g >> 12];
-}
-
-// meta[0] = number of tasks, meta[1] = number of multi-task buckets (biglist length)
-__global__ __launch_bounds__(256) void k_msm_task_meta(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
-                                                       const uint32_t *__restrict__ tblockoff, uint32_t total, uint32_t *__restrict__ meta,
-                                                       uint32_t *__restrict__ biglist) {
-    uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    if (g == total - 1) meta[0] = scan_at(toff, tblockoff, g) + ntask[g];
-    // multi-task buckets: 2..8 tasks are folded by one lane each, more by a wave each
-    uint32_t nt = ntask[g];
-    if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
-    else if (nt > 1) biglist[total - 1 - atomicAdd(&meta[140], 1u)] = g;  // small list grows down from the end
 }
 
 // Tasks are processed in order of decreasing length so that the 64 lanes of a wave run chains of
@@ -441,19 +423,29 @@ HALO_DEV void task_locate(const uint32_t *__restrict__ toff, const uint32_t *__r
     len = counts[g] - first;
     if (len > kmax) len = kmax;
 }
-__global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
-                                                       const uint32_t *__restrict__ counts, uint32_t total_buckets, uint32_t kmax,
-                                                       uint32_t *__restrict__ meta, uint32_t *__restrict__ task_g) {
+// Also: meta[0] = number of tasks; the multi-task buckets are listed for the combine kernel (by the lane that holds a
+// bucket's first task): meta[1] of them with more than 8 tasks from the front of biglist, meta[140] with 2..8 from its end.
+__global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                                                       const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ counts,
+                                                       uint32_t total_buckets, uint32_t kmax, uint32_t *__restrict__ meta,
+                                                       uint32_t *__restrict__ task_g, uint32_t *__restrict__ biglist) {
     __shared__ uint32_t bins[KMAX + 1];
-    if (blockIdx.x * 256 >= meta[0]) return;  // the grid covers the worst case; blocks past the last task leave at once
+    uint32_t ntasks = scan_at(toff, tblockoff, total_buckets - 1) + ntask[total_buckets - 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) meta[0] = ntasks;
+    if (blockIdx.x * 256 >= ntasks) return;  // the grid covers the worst case; blocks past the last task leave at once
     if (threadIdx.x <= KMAX) bins[threadIdx.x] = 0;
     __syncthreads();
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < meta[0]) {
+    if (t < ntasks) {
         uint32_t g, len;
         task_locate(toff, tblockoff, counts, total_buckets, kmax, t, g, len);
-        task_g[t] = g | ((KMAX - len) << 24);  // bucket id (< 2^20) and bin = 64 - len
+        task_g[t] = g | ((KMAX - len) << 24);  // bucket id (< 2^24) and bin = 64 - len
         atomicAdd(&bins[KMAX - len], 1u);
+        if (t == scan_at(toff, tblockoff, g)) {  // first task of its bucket
+            uint32_t nt = ntask[g];
+            if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
+            else if (nt > 1) biglist[total_buckets - 1 - atomicAdd(&meta[140], 1u)] = g;
+        }
     }
     __syncthreads();
     if (threadIdx.x <= KMAX && bins[threadIdx.x]) atomicAdd(&meta[2 + threadIdx.x], bins[threadIdx.x]);
@@ -514,29 +506,28 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     xyzz_store(partial + XYZZ_WORDS * (size_t)t, acc);
 }
 
-// one lane per bucket with 2..8 tasks (grid-stride over the tail of biglist)
-__global__ __launch_bounds__(256) void k_msm_combine_small(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
-                                                          const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                          const uint32_t *__restrict__ biglist, uint32_t total,
-                                                          uint32_t *__restrict__ partial) {
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < meta[140]; b += gridDim.x * 256) {
-        uint32_t g = biglist[total - 1 - b];
-        uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
-        XyzzN acc = xyzz_load(partial + XYZZ_WORDS * (size_t)t0);
-#pragma unroll 1
-        for (uint32_t j = 1; j < nt; j++) {
-            XyzzN q = xyzz_load(partial + XYZZ_WORDS * (size_t)(t0 + j));
-            xyzz_add(acc, q);
-        }
-        xyzz_store(partial + XYZZ_WORDS * (size_t)t0, acc);
-    }
-}
-// one wave per bucket with more than 8 tasks (grid-stride over biglist): partial[toff(g)] <- sum of its partials
-__global__ __launch_bounds__(64) void k_msm_combine_big(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
-                                                        const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                        const uint32_t *__restrict__ biglist, uint32_t *__restrict__ partial) {
+// Folds the partials of multi-task buckets into the first one.  Blocks [0, small_blocks): one lane per bucket with 2..8
+// tasks (grid-stride over the tail of biglist); the others: one wave per bucket with more than 8 tasks.
+__global__ __launch_bounds__(64) void k_msm_combine(const uint32_t *__restrict__ ntask, const uint32_t *__restrict__ toff,
+                                                    const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
+                                                    const uint32_t *__restrict__ biglist, uint32_t total, uint32_t small_blocks,
+                                                    uint32_t *__restrict__ partial) {
     uint32_t lane = threadIdx.x;
-    for (uint32_t b = blockIdx.x; b < meta[1]; b += gridDim.x) {
+    if (blockIdx.x < small_blocks) {
+        for (uint32_t b = blockIdx.x * 64 + lane; b < meta[140]; b += small_blocks * 64) {
+            uint32_t g = biglist[total - 1 - b];
+            uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
+            XyzzN acc = xyzz_load(partial + XYZZ_WORDS * (size_t)t0);
+#pragma unroll 1
+            for (uint32_t j = 1; j < nt; j++) {
+                XyzzN q = xyzz_load(partial + XYZZ_WORDS * (size_t)(t0 + j));
+                xyzz_add(acc, q);
+            }
+            xyzz_store(partial + XYZZ_WORDS * (size_t)t0, acc);
+        }
+        return;
+    }
+    for (uint32_t b = blockIdx.x - small_blocks; b < meta[1]; b += gridDim.x - small_blocks) {
         uint32_t g = biglist[b];
         uint32_t nt = ntask[g], t0 = scan_at(toff, tblockoff, g);
         XyzzN acc = xyzz_inf();
@@ -1103,6 +1094,8 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     dim3 gridh((unsigned)(Wt * nchunks)), b1024(1024);
     size_t lds_bytes = (size_t)p.B * 4;
     uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
+    // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
+    uint32_t kmax = msm_kmax(ctx, n);
     // large MSMs: two-level sort (coarse runs, then a fine sort per run) -- every store lands next to recent ones
     uint32_t NC = p.B >> FINE_BITS;
     bool two_level = vec && p.B >= (1u << FINE_BITS) && (size_t)Wt * NC <= 4096 && ws.d_presort &&
@@ -1118,40 +1111,32 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         HALO_HIP(hipMemsetAsync(ws.d_blockoff, 0, 1024 * 4, s));  // the fine pass writes absolute starts
         if (packed)
             HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
-                        offs, ws.d_counts, ws.d_starts, ws.d_sorted);
+                        offs, kmax, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_sorted);
         else
             HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<false>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
-                        offs, ws.d_counts, ws.d_starts, ws.d_sorted);
+                        offs, kmax, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_sorted);
     } else {
         HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);
         HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
-                    ws.d_counts);
+                    kmax, ws.d_counts, ws.d_ntask);
         HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_counts, (uint32_t)total, ws.d_starts, ws.d_blockoff);
         HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_blockoff, nblocks);
         HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
                     ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
     }
-    dim3 gridb((unsigned)((total + 255) / 256));
     HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
-    // chain bound per lane: 64 where the launch is throughput-bound, 16 where it is latency-bound
-    uint32_t kmax = msm_kmax(ctx, n);
-    HALO_LAUNCH(ctx, "k_msm_ntasks", k_msm_ntasks, gridb, b256, 0, ws.d_counts, (uint32_t)total, kmax, ws.d_ntask);
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
-    HALO_LAUNCH(ctx, "k_msm_task_meta", k_msm_task_meta, gridb, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, (uint32_t)total, ws.d_meta,
-                ws.d_biglist);
     size_t max_tasks = total + n * (size_t)Wt / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
-    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax, ws.d_meta,
-                ws.d_task_g);
+    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax,
+                ws.d_meta, ws.d_task_g, ws.d_biglist);
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
     HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
                 ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
-    HALO_LAUNCH(ctx, "k_msm_combine_small", k_msm_combine_small, dim3(512), b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
-                ws.d_biglist, (uint32_t)total, ws.d_buckets);
-    HALO_LAUNCH(ctx, "k_msm_combine_big", k_msm_combine_big, dim3(1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta,
-                ws.d_biglist, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
+                (uint32_t)total, 512u, ws.d_buckets);
     uint32_t L, nseg;
     int logL = 0;
     // buckets per lane (L) against segments per window: a lane's 2L serial adds are all useful work,
