@@ -69,9 +69,17 @@ HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c
 constexpr uint32_t DIGIT_NONE = 0xFFFFu;
 
 // Windows [w0, w1) are written (a window shard still walks the carry chain from window 0).
+// Block 0 also clears the launch's small state (meta: 256 words; zero_b: the 1024 block offsets where the sort writes
+// absolute bucket starts) -- nothing reads either before the sort passes that follow.
 __global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int w0, int w1,
-                                                    uint32_t B, uint16_t *__restrict__ digits) {
+                                                    uint32_t B, uint16_t *__restrict__ digits, uint32_t *__restrict__ meta,
+                                                    uint32_t *__restrict__ zero_b) {
     __shared__ uint32_t sw[256 * 9];
+    if (blockIdx.x == 0) {
+        meta[threadIdx.x] = 0;
+        if (zero_b)
+            for (int k = 0; k < 4; k++) zero_b[threadIdx.x + 256 * k] = 0;
+    }
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Fe s = fe_load(scalars + 4 * (size_t)i);
@@ -1081,7 +1089,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     for (int b = 0; b < p.batch; ++b) {
         offs.v[b] = members.base_off[b];
         HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, gridn, b256, 0, members.scalars[b], mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
-                    d_digits + (size_t)b * Wm * n);
+                    d_digits + (size_t)b * Wm * n, ws.d_meta, ws.d_blockoff);
     }
     // one block per (window, chunk): about one block per CU, chunks of at least 1024 scalars
     uint32_t nchunks = 256u / Wt;
@@ -1108,7 +1116,6 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         int packed = n <= ((size_t)1 << 21) ? 1 : 0;  // index (21 bits) + fine bucket bits (10) + sign fit one word
         HALO_LAUNCH(ctx, "k_msm_coarse_scatter", k_msm_coarse_scatter, gridh, b1024, 0, d_digits, (uint32_t)n, NC, nchunks, chunk_len, chist, cstart,
                     packed, ws.d_presort);
-        HALO_HIP(hipMemsetAsync(ws.d_blockoff, 0, 1024 * 4, s));  // the fine pass writes absolute starts
         if (packed)
             HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
                         offs, kmax, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_sorted);
@@ -1124,7 +1131,6 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
                     ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
     }
-    HALO_HIP(hipMemsetAsync(ws.d_meta, 0, 1024, s));
     HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
     HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
     size_t max_tasks = total + n * (size_t)Wt / kmax + 1;
