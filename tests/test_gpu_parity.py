@@ -441,6 +441,46 @@ def test_msm_randomised_configurations(hal, ctx16k, urs4096):
         ctx16k.set_window_bits(0); ctx16k.set_sort_mode(-1)
 
 
+def test_msm_batched_window_shards_2_20(hal, ctx1m):
+    """What one rank of an 8-rank window-sharded run launches (4 MSMs x 2 of the 16 windows), for every rank: the
+    partials of each MSM add up to the unsharded result."""
+    import torch
+    n = 1 << 20
+    ds = []
+    for i in range(4):
+        d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        ctx1m.rng_scalars_dev(0x48414C4F00000002 + 4 * i * n * 0x9E3779B97F4A7C15 & (2**64 - 1), n, d.data_ptr())
+        ds.append(d)
+    want = [ctx1m.msm_dev(d.data_ptr(), n).tolist() for d in ds]
+    ptrs = [d.data_ptr() for d in ds]
+    partials = []
+    for rank in range(8):
+        ctx1m.msm_dev_batch_begin(rank % 4, ptrs, n, part=rank, parts=8)
+        partials.append(ctx1m.msm_dev_batch_end(rank % 4, 4))
+    for b in range(4):
+        assert hal.point_sum(np.stack([p[b] for p in partials])).tolist() == want[b]
+
+
+def test_msm_2_22_split_linearity():
+    """n = 2^22 > 2^21: the two-level sort can no longer pack index, sign and bucket bits into one word and looks the
+    digits up instead; checked by the size-independent split property (BASELINE config 5 scale on one rank: 2^21)."""
+    import torch
+    import halo_accumulation_amd as h
+    n = 1 << 22
+    c = h._lib.Context(urs_n=n)
+    try:
+        d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        c.rng_scalars_dev(0x48414C4F00000005, n, d.data_ptr())
+        full = c.msm_dev(d.data_ptr(), n)
+        lo = c.msm_dev(d.data_ptr(), n // 2)
+        hi = c.msm_dev(d.data_ptr() + (n // 2) * 32, n // 2, off=n // 2)
+        assert h._lib.point_sum(np.stack([lo, hi])).tolist() == full.tolist()
+        q1 = c.msm_dev(d.data_ptr(), n // 4)   # 2^20: the packed form on the same context
+        assert h._lib.point_sum(np.stack([q1, c.msm_dev(d.data_ptr() + (n // 4) * 32, n // 4, off=n // 4)])).tolist() == lo.tolist()
+    finally:
+        c.close()
+
+
 def test_msm_batch_2_18_and_misuse(hal, ctx1m):
     import torch
     n = 1 << 18
