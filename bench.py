@@ -48,7 +48,12 @@ def main():
     # HALO_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("HALO_BENCH_BACKEND", "nccl")
     gpu = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # HALO_BENCH_FORCE_DIST=1: one rank, but with the process group and the all-gather of the N > 1 path (RCCL rehearsal)
+    force_dist = world == 1 and os.environ.get("HALO_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
@@ -88,7 +93,10 @@ def main():
     # one launch's low-occupancy tail (bucket reduce, D2H of the window sums, host Horner) overlaps the
     # next one's sort/accumulate kernels.  Every MSM is completed (and, for N > 1, all-gathered and
     # combined) inside the timed region.
-    gather = ShardedMsm(None, h._lib.point_sum, device=coll_dev)
+    gather = ShardedMsm(None, h._lib.point_sum, device=coll_dev, always_collective=force_dist)
+    if world > 1 or force_dist:
+        # first collective now: the communicator's lazy allocations happen before any launch graph exists
+        gather.gather_batch([np.zeros(12, dtype=np.uint64)] * batch)
 
     cfg = {"depth": args.depth}
     outs = [None] * batch  # latest combined result per scalar set
@@ -117,7 +125,7 @@ def main():
             finish()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +138,7 @@ def main():
     dt = time.perf_counter() - t0
     out = outs[0]
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -249,12 +257,12 @@ def main():
         if not window_mode:
             full.close()
         assert ok, "sharded MSM differs from the single-GPU MSM"
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -35,11 +35,12 @@ def window_range(W: int, rank: int, world: int):
 class ShardedMsm:
     """partial_fn() -> (12,) uint64 Jacobian partial of this rank; sum_fn(points (P,12)) -> (12,)."""
 
-    def __init__(self, partial_fn, sum_fn, device=None):
+    def __init__(self, partial_fn, sum_fn, device=None, always_collective=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.partial_fn, self.sum_fn = partial_fn, sum_fn
+        self.always_collective = always_collective and dist.is_initialized()  # run the all-gather even on one rank (rehearsals)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = device if device is not None else torch.device("cpu")
@@ -53,7 +54,7 @@ class ShardedMsm:
         if k == 0:
             return []
         local = np.ascontiguousarray(np.stack(parts), dtype=np.uint64)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return [local[i] for i in range(k)]
         torch = self.torch
         send = torch.from_numpy(local.view(np.int64).reshape(-1)).to(self.device)
