@@ -218,6 +218,25 @@ def main():
             cpu_dt = (time.perf_counter() - t0) / args.cpu_msms
             assert out.tolist() == want.tolist(), "GPU MSM differs from the CPU restatement"
             result["bit_exact_vs_cpu"] = True
+            # the same port on many cores: independent MSMs, one per thread (ctypes releases the GIL); a reported
+            # figure next to the single-thread one, which is how the reference runs
+            import threading
+            T = max(1, min(16, os.cpu_count() or 1))  # the CPU share of a one-GPU box
+            box = [None] * T
+
+            def one(k):
+                box[k] = orc.msm_affine(gs, sc_all)
+
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=one, args=(k,)) for k in range(T)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            par_dt = time.perf_counter() - t0
+            assert all(b.tolist() == want.tolist() for b in box)
+            result["cpu_baseline_all_threads"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port",
+                                                   "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
             result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port",
                                       "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
                                       "host_cpus": os.cpu_count()}
