@@ -69,29 +69,42 @@ HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c
 constexpr uint32_t DIGIT_NONE = 0xFFFFu;
 
 // Windows [w0, w1) are written (a window shard still walks the carry chain from window 0).
-// Block 0 also clears the launch's small state (meta: 256 words; zero_b: the 1024 block offsets where the sort writes
-// absolute bucket starts) -- nothing reads either before the sort passes that follow.
-__global__ __launch_bounds__(256) void k_msm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, int c, int w0, int w1,
-                                                    uint32_t B, uint16_t *__restrict__ digits, uint32_t *__restrict__ meta,
+// Block (0, 0) also clears the launch's small state (meta: 256 words; zero_b: the 1024 block offsets where the sort
+// writes absolute bucket starts) -- nothing reads either before the sort passes that follow.  blockIdx.y = member
+// of a batched launch.  A window shard (w0 > 0) does not walk the carry chain from window 0: the carry into w0 is
+// decided by the nearest lower window whose raw digit differs from B (raw < B: 0, raw > B: 1, raw == B: passes on).
+struct MemberScalars { const uint64_t *p[MSM_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void k_msm_recode(MemberScalars scalars, int mont, uint32_t n, int c, int w0, int w1, uint32_t B,
+                                                    uint16_t *__restrict__ digits, uint32_t *__restrict__ meta,
                                                     uint32_t *__restrict__ zero_b) {
     __shared__ uint32_t sw[256 * 9];
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         meta[threadIdx.x] = 0;
         if (zero_b)
             for (int k = 0; k < 4; k++) zero_b[threadIdx.x + 256 * k] = 0;
     }
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Fe s = fe_load(scalars + 4 * (size_t)i);
+    const uint64_t *src = nullptr;
+#pragma unroll
+    for (int b = 0; b < MSM_MAX_BATCH; b++) src = ((int)blockIdx.y == b) ? scalars.p[b] : src;
+    uint16_t *out = digits + (size_t)blockIdx.y * (size_t)(w1 - w0) * n;
+    Fe s = fe_load(src + 4 * (size_t)i);
     if (mont) s = fe_from_mont<FrCfg>(s);  // arkworks `into_bigint`
     uint32_t *my = sw + threadIdx.x * 9;
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
     uint32_t carry = 0;
-    for (int w = 0; w < w1; w++) {
+    for (int j = w0 - 1; j >= 0; j--) {
+        uint32_t bit = (uint32_t)j * (uint32_t)c;
+        uint64_t two = (uint64_t)my[bit >> 5] | ((uint64_t)my[(bit >> 5) + 1] << 32);
+        uint32_t raw = (uint32_t)(two >> (bit & 31)) & ((1u << c) - 1u);
+        if (raw != B) { carry = raw > B ? 1u : 0u; break; }
+    }
+    for (int w = w0; w < w1; w++) {
         Digit d = next_digit(my, w, c, B, carry);
-        if (w >= w0) digits[(size_t)(w - w0) * n + i] = (uint16_t)(d.mag ? ((d.mag - 1) | (d.neg << 15)) : DIGIT_NONE);
+        out[(size_t)(w - w0) * n + i] = (uint16_t)(d.mag ? ((d.mag - 1) | (d.neg << 15)) : DIGIT_NONE);
     }
 }
 
@@ -1086,11 +1099,13 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     dim3 gridn((unsigned)((n + 255) / 256)), b256(256);
     uint16_t *d_digits = reinterpret_cast<uint16_t *>(ws.d_canon);  // n * Wt * 2 bytes, layout [member][w][i]
     MemberOffsets offs{};
+    MemberScalars srcs{};
     for (int b = 0; b < p.batch; ++b) {
         offs.v[b] = members.base_off[b];
-        HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, gridn, b256, 0, members.scalars[b], mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
-                    d_digits + (size_t)b * Wm * n, ws.d_meta, ws.d_blockoff);
+        srcs.p[b] = members.scalars[b];
     }
+    HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, dim3(gridn.x, (unsigned)p.batch), b256, 0, srcs, mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
+                d_digits, ws.d_meta, ws.d_blockoff);
     // one block per (window, chunk): about one block per CU, chunks of at least 1024 scalars
     uint32_t nchunks = 256u / Wt;
     if (nchunks < 1) nchunks = 1;
