@@ -4,7 +4,7 @@ K x verifier + 1 x decider).  Prints one JSON line; results are checked by the s
 (every verifier and the decider must accept)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import halo_accumulation_amd as h
 from halo_accumulation_amd import acc as A
 

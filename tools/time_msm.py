@@ -2,16 +2,15 @@
 import sys, time, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import halo_accumulation_amd as h
-import orc
 import torch
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n = 1 << lg
 t = time.time(); ctx = h._lib.Context(urs_n=n); print("ctx urs %d: %.2fs" % (n, time.time() - t), flush=True)
-sc, _ = orc.rng_scalars(2, n)
-d = torch.from_numpy(sc.view(np.int64)).cuda()
+d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+ctx.rng_scalars_dev(2, n, d.data_ptr())  # the library's own SplitMix64 generator
 for c in ([0] if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(",")]):
     ctx.set_window_bits(c)
     ctx.msm_dev(d.data_ptr(), n)

@@ -2,17 +2,19 @@
 import sys, time, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import halo_accumulation_amd as h
 from halo_accumulation_amd import pcdl
-import orc
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 hiding = len(sys.argv) > 2 and sys.argv[2] == "hiding"
 n = 1 << lg; d = n - 1
 t = time.time(); ctx = h._lib.Context(urs_n=n); print("ctx urs %d: %.2fs" % (n, time.time() - t), flush=True)
-coeffs, s = orc.rng_scalars(3, n)
-zw, _ = orc.rng_scalars(s, 2)
+import torch
+_d = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
+ctx.rng_scalars_dev(3, n + 2, _d.data_ptr())  # n coefficients, then z, w from the library's own generator
+_co = np.ascontiguousarray(_d.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
+coeffs, zw = np.ascontiguousarray(_co[:n]), np.ascontiguousarray(_co[n:])
 z, w = zw[0], (zw[1] if hiding else None)
 t = time.time(); C = pcdl.commit(ctx, coeffs, d, w); print("commit %.2f ms" % ((time.time() - t) * 1e3))
 pi = pcdl.open(ctx, [7], coeffs, C, d, z, w)  # warm-up
