@@ -165,6 +165,15 @@ struct Point {  // Jacobian, Z = 0 infinity
     }
     static Point generator() { return from_affine(-Fq::one(), Fq::one().dbl()); }  // (-1, 2)
     bool is_inf() const { return Z.is_zero(); }
+    // Y^2 = X^3 + 5 Z^6 with coordinates below the modulus (what ark-ec's checked deserialisation guarantees for
+    // every `Projective` the reference ever holds); infinity is on the curve
+    bool on_curve() const {
+        if (Fq::geq(X.l, FqP::M) || Fq::geq(Y.l, FqP::M) || Fq::geq(Z.l, FqP::M)) return false;
+        if (is_inf()) return true;
+        Fq z2 = Z.sqr(), z6 = z2.sqr() * z2;
+        Fq five = Fq::from_u64(5);
+        return Y.sqr() == X.sqr() * X + five * z6;
+    }
 
     Point dbl() const {  // dbl-2009-l
         if (is_inf()) return *this;

@@ -6,6 +6,7 @@
 //
 // What stays on the host, exactly as in the reference: Fiat-Shamir hashing (rho_0!/rho_1!),
 // challenge inversion, the O(lg n) succinct check and the struct packing.
+#include <atomic>
 #include <memory>
 #include <thread>
 
@@ -167,6 +168,17 @@ static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point 
     return halo_ipa_finish(st, pf_U(proof, lg_n), pf_c(proof, lg_n));  // :230-231
 }
 
+static bool scalar_ok(const Fr &s) { return !Fr::geq(s.l, host::FrP::M); }
+// every point of the blob on the curve, every scalar canonical, flag word 0 or 1
+static bool proof_wellformed(uint64_t *proof, size_t lg_n) {
+    if (proof[0] > 1) return false;
+    for (size_t i = 0; i < lg_n; ++i)
+        if (!Point::load(pf_L(proof, i)).on_curve() || !Point::load(pf_R(proof, lg_n, i)).on_curve()) return false;
+    if (!Point::load(pf_U(proof, lg_n)).on_curve() || !scalar_ok(Fr::load(pf_c(proof, lg_n)))) return false;
+    if (proof[0] && (!Point::load(pf_Cbar(proof, lg_n)).on_curve() || !scalar_ok(Fr::load(pf_wp(proof, lg_n))))) return false;
+    return true;
+}
+
 // pcdl.rs:252-314.  The 2 lg n + O(1) scalar multiplications are one interleaved host MSM.
 static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c,
                                std::vector<Fr> *xis_out, Point *U_out) {
@@ -176,6 +188,10 @@ static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr
     if (d + 1 > ctx->n) return fail_reject("d was larger than D!");
     size_t lg_n = ilog2(n);
     if (proof[1] != lg_n) return fail_reject("proof length does not match d");
+    // Everything below reads exactly proof_words(lg_n) words.  The blob is verifier input: the reference's typed
+    // `PallasPoint`/`PallasScalar` values are on the curve / below the modulus by construction, here that is checked.
+    if (!C.on_curve() || !scalar_ok(z) || !scalar_ok(v)) return fail_reject("instance holds an invalid point or scalar");
+    if (!proof_wellformed(proof, lg_n)) return fail_reject("proof holds an invalid point or scalar");
     const PublicPoints &pp = public_points();
     Point C_prime = C;
     if (proof[0]) {
@@ -280,6 +296,13 @@ static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t
     // each): one thread per instance; errors are reported in instance order like the serial loop
     struct CheckResult { int rc = HALO_OK; std::string err; std::vector<Fr> xis; Point U; };
     std::vector<CheckResult> res(m);
+    // The instances are laid out with the stride of degree d.  An instance that claims another degree (or whose
+    // proof claims another length) would be read past its end: it is rejected here, before anything is parsed --
+    // the reference fails on it too (acc.rs:169, after its typed, bounds-safe succinct check).
+    for (size_t i = 0; i < m; ++i) {
+        const uint64_t *q = qs + i * iw;
+        if ((size_t)q[12] != d || q[22] != lg) return fail_reject("d_i != d");  // :169
+    }
     auto run_one = [&](size_t i) {
         const uint64_t *q = qs + i * iw;
         res[i].rc = succinct_check_host(ctx, Point::load(q), (size_t)q[12], Fr::load(q + 13), Fr::load(q + 17), q + 21, &res[i].xis,
@@ -288,16 +311,22 @@ static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t
     };
     if (m <= 1) {
         for (size_t i = 0; i < m; ++i) run_one(i);
-    } else {
+    } else {  // a bounded pool: at most 16 host threads pull instances off a shared counter
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nthreads = hw ? hw : 4;
+        if (nthreads > 16) nthreads = 16;
+        if (nthreads > m) nthreads = m;
+        std::atomic<size_t> next{0};
+        auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < m;) run_one(i); };
         std::vector<std::thread> th;
-        for (size_t i = 0; i < m; ++i) th.emplace_back(run_one, i);
+        for (size_t t = 1; t < nthreads; ++t) th.emplace_back(worker);
+        worker();
         for (auto &t : th) t.join();
     }
     for (size_t i = 0; i < m; ++i) {
         if (res[i].rc) { set_error(res[i].err); return res[i].rc; }
         hs->xis.push_back(std::move(res[i].xis));
         Us.push_back(res[i].U);
-        if ((size_t)(qs + i * iw)[12] != d) return fail_reject("d_i != d");  // :169
     }
     // :173  alpha = rho_1(hs): h_0 Some(poly), hs Vec<HPoly>, alpha None, alphas empty
     Transcript t;
@@ -452,6 +481,9 @@ int halo_acc_verifier(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t m, con
     size_t lg = ilog2(d + 1);
     const uint64_t *piV = acc + instance_words(lg);
     Fr h0[2] = {Fr::load(piV), Fr::load(piV + 4)};
+    if (!Point::load(piV + 8).on_curve() || !Point::load(acc).on_curve() || !scalar_ok(h0[0]) || !scalar_ok(h0[1]) ||
+        !scalar_ok(Fr::load(piV + 20)) || !scalar_ok(Fr::load(acc + 13)) || !scalar_ok(Fr::load(acc + 17)))
+        return fail_reject("accumulator holds an invalid point or scalar");
     Point C_bar_p;
     Fr z_p;
     AccHPolys hs;

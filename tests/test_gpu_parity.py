@@ -33,6 +33,21 @@ def canon(j):
     return orc.point_canonical(j)
 
 
+def unnormalise(jac, lam):
+    """(X, Y, Z) -> (lam^2 X, lam^3 Y, lam Z): the same point with Z != 1, as the reference's `Projective`
+    values are after any arithmetic (group.rs:18-21 takes them un-normalised, acc.rs:178)."""
+    L = orc.lib()
+    l2, l3, o = orc.z(4), orc.z(4), np.array(jac, dtype=np.uint64).copy()
+    lam = np.ascontiguousarray(lam, dtype=np.uint64)
+    L.orc_fq_mul(orc.ptr(lam), orc.ptr(lam), orc.ptr(l2))
+    L.orc_fq_mul(orc.ptr(l2), orc.ptr(lam), orc.ptr(l3))
+    for off, f in ((0, l2), (4, l3), (8, lam)):
+        t = orc.z(4)
+        L.orc_fq_mul(orc.ptr(np.ascontiguousarray(o[off:off + 4])), orc.ptr(f), orc.ptr(t))
+        o[off:off + 4] = t
+    return o
+
+
 # ------------------------------------------------------------------ K11 + group law
 def test_urs_kernel_reproduces_consts_table(ctx16k, kat):
     """All 16,384 GS entries of consts.rs, bit-for-bit, out of the HIP fixed-base kernel."""
@@ -104,11 +119,16 @@ def test_point_ops(ctx16k, urs4096):
     # a_i = k_i * G_i (Jacobian, un-normalised on purpose: scale by lambda^2, lambda^3)
     a = np.zeros((n, 12), dtype=np.uint64)
     b = np.zeros((n, 12), dtype=np.uint64)
+    lams, _ = orc.rng_scalars(s + 1, 2 * n)  # any limb pattern < 2^254 + small is a valid Fq Montgomery element too
+    lams[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
     for i in range(n):
         orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(a[i]))
         orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i + n]), orc.ptr(b[i]))
-    # special cases: P + P, P + (-P), inf + P, P + inf
-    b[0] = a[0]
+        if i % 4 != 3:  # three in four inputs have Z != 1 (every fourth keeps the Z = 1 fast paths covered)
+            a[i] = unnormalise(a[i], lams[i])
+            b[i] = unnormalise(b[i], lams[n + i])
+    # special cases: P + P (two different representatives of the same point), P + (-P), inf + P, P + inf
+    b[0] = unnormalise(a[0], lams[5])
     neg = orc.z(12); orc.lib().orc_point_mul(orc.ptr(a[1]), orc.ptr(orc.fr_to_mont(pm.R_ORDER - 1)), orc.ptr(neg)); b[1] = neg
     inf = np.array([1, 0, 0, 0] * 0 + list(a[2][:8]) + [0, 0, 0, 0], dtype=np.uint64)
     a[2] = inf
@@ -254,11 +274,14 @@ def test_msm_points_matches_point_dot(ctx16k, urs4096):
     m = 300
     pts = np.zeros((m, 12), dtype=np.uint64)
     ks, s = orc.rng_scalars(31, m)
+    lams, _ = orc.rng_scalars(s + 7, m)
+    lams[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
     for i in range(m):
         j = orc.z(12); orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(j))
-        # un-normalise: multiply by a scalar so Z != 1 through the oracle's own routine? keep Z = 1 for most,
-        pts[i] = j
+        pts[i] = j if i % 5 == 0 else unnormalise(j, lams[i])  # Z != 1 for four in five
     pts[7] = np.array(list(pts[7][:8]) + [0, 0, 0, 0], dtype=np.uint64)  # infinity
+    pts[9] = pts[8]  # a repeated (differently scaled below) point
+    pts[9] = unnormalise(pts[9], lams[9])
     sc, _ = orc.rng_scalars(s, m + 5)
     want = orc.msm_jac(pts, sc[:m])
     assert ctx16k.msm_points(pts, sc).tolist() == want.tolist()
@@ -477,6 +500,54 @@ def test_msm_2_22_split_linearity():
         assert h._lib.point_sum(np.stack([lo, hi])).tolist() == full.tolist()
         q1 = c.msm_dev(d.data_ptr(), n // 4)   # 2^20: the packed form on the same context
         assert h._lib.point_sum(np.stack([q1, c.msm_dev(d.data_ptr() + (n // 4) * 32, n // 4, off=n // 4)])).tolist() == lo.tolist()
+    finally:
+        c.close()
+
+
+def test_msm_2_24_shards_and_oracle_slice(hal):
+    """BASELINE config 5 (n = 2^24), everything one GPU can say about it: the key comes from the main.rs:18-45
+    derivation on the device, the scalars from seed ...05; split-linearity; 8 window shards and 8 index shards
+    (the per-rank shares of an 8-GPU run) each sum to the unsharded point; an index shard computed by a context
+    of its own (as a rank would hold it) equals the same block of the big context; and a 2^18-point slice is
+    compared with the CPU oracle."""
+    import torch
+    n = 1 << 24
+    c = hal.Context(urs_n=n)
+    try:
+        d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        c.rng_scalars_dev(0x48414C4F00000005, n, d.data_ptr())
+        base = d.data_ptr()
+        full = c.msm_dev(base, n)
+        assert canon(full) is not None
+        lo = c.msm_dev(base, n // 2)
+        hi = c.msm_dev(base + (n // 2) * 32, n // 2, off=n // 2)
+        assert hal.point_sum(np.stack([lo, hi])).tolist() == full.tolist()
+        # 8 window shards (halo_msm_dev_begin_part): what bench.py --gpus 8 --shard window gives each rank
+        parts = []
+        for r in range(8):
+            c.msm_dev_begin(r % 4, base, n, part=r, parts=8)
+            parts.append(c.msm_dev_end(r % 4))
+        assert hal.point_sum(np.stack(parts)).tolist() == full.tolist()
+        # 8 index shards (SURVEY 8e): blocks of 2^21 bases and scalars
+        from halo_accumulation_amd.sharded import shard_range
+        parts = []
+        for r in range(8):
+            a, b = shard_range(n, r, 8)
+            parts.append(c.msm_dev(base + a * 32, b - a, off=a))
+        assert hal.point_sum(np.stack(parts)).tolist() == full.tolist()
+        # rank 5's shard from a context of its own: G_i = hash(i + 2) starts at its block (main.rs:35-45)
+        a, b = shard_range(n, 5, 8)
+        own = hal.Context(urs_n=b - a, first_index=2 + a)
+        try:
+            assert own.msm_dev(base + a * 32, b - a).tolist() == parts[5].tolist()
+        finally:
+            own.close()
+        # oracle on a slice that crosses nothing special: 2^18 points from offset 5 * 2^21 + 12345
+        off, m = a + 12345, 1 << 18
+        gs = c.read_bases(off, m)
+        sc = np.ascontiguousarray(d[off * 4:(off + m) * 4].cpu().numpy().view(np.uint64).reshape(m, 4))
+        assert gs[:2].tolist() == orc.urs_affine(2 + off, 2).tolist()
+        assert c.msm_dev(base + off * 32, m, off=off).tolist() == orc.msm_affine(gs, sc).tolist()
     finally:
         c.close()
 

@@ -251,25 +251,91 @@ def test_open_2_17_both_strategies_agree(hal):
         c.close()
 
 
-def test_acc_chain_2_20_completeness(hal):
-    """BASELINE config 4 shape at full size, two steps of benches/acc.rs:76-98: random_instance +
-    prover, each accepted by the verifier, then the decider (pcdl::check with the n = 2^20 MSM)."""
+def test_acc_chain_2_20_64_instances(hal):
+    """BASELINE config 4 at full size, the whole shape of benches/acc.rs:64-98 with k = 64: 64 x (random_instance +
+    prover([prev_acc.into(), q])), then 64 x verifier + 1 x decider (the "fast" check), plus a few deciders of
+    earlier accumulators (the "slow" check, benches/acc.rs:100-106) and rejection of tampered inputs."""
+    import json, os, time
     from halo_accumulation_amd import acc as A
-    n = 1 << 20
+    n, K = 1 << 20, 64
     d = n - 1
     c = hal._lib.Context(urs_n=n)
     try:
         rng = [0x48414C4F00000004]
-        acc = None
-        for _ in range(2):
+        accs, qss, acc = [], [], None
+        t0 = time.perf_counter()
+        for _ in range(K):
             q = A.random_instance(c, rng, d)
             qs = [q] if acc is None else [A.instance_from_accumulator(c, acc, d), q]
             acc = A.prover(c, rng, d, qs)
-            A.verifier(c, d, qs, acc)
-        A.decider(c, acc)
-        bad = acc.copy(); bad[13] ^= 1  # z
+            accs.append(acc); qss.append(qs)
+        t_chain = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for a, qs in zip(accs, qss):
+            A.verifier(c, d, qs, a)
+        t_ver = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        A.decider(c, accs[-1])
+        t_dec = time.perf_counter() - t0
+        for a in accs[:3]:
+            A.decider(c, a)
+        bad = accs[-1].copy(); bad[13] ^= 1  # z
         with pytest.raises(ValueError):
             A.decider(c, bad)
+        with pytest.raises(ValueError):
+            A.verifier(c, d, qss[-1], accs[-2])  # an accumulator of other instances
+        # an instance that claims another degree must be rejected before it is parsed (acc.rs:169)
+        q_bad = qss[-1][1].copy(); q_bad[12] = 2 * n - 1; q_bad[22] = 21
+        with pytest.raises(ValueError):
+            A.verifier(c, d, [qss[-1][0], q_bad], accs[-1])
+        # a proof point off the curve is rejected, not computed with
+        q_bad = qss[-1][1].copy(); q_bad[21 + 2] ^= 1  # X of L_0
+        with pytest.raises(ValueError):
+            A.verifier(c, d, [qss[-1][0], q_bad], accs[-1])
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "asdl64_test_timing.json"), "w") as f:
+            json.dump({"config": "ASDL 64 accumulated instances n=2^20 (tests/test_gpu_pcdl_acc.py)", "prover_chain_s": t_chain,
+                       "verifier_ms_each": t_ver / K * 1e3, "decider_ms": t_dec * 1e3}, f)
+    finally:
+        c.close()
+
+
+def test_open_2_19_matches_oracle_fixture(hal):
+    """pcdl::open at n = 2^19 against the oracle's proof (tests/golden/open_2_19.json, generated in the build
+    container by tests/golden/make_open_fixture.py): the first fold of this size runs k_fold_points with two
+    points per lane sharing one inversion (m = 2^18, ipa.hip ipa_fold_points) -- compared bit for bit with the
+    CPU restatement's double-and-add fold (pcdl.rs:216-224), hiding and non-hiding."""
+    import hashlib, json, os
+    from halo_accumulation_amd import pcdl
+    with open(os.path.join(ROOT, "tests", "golden", "open_2_19.json")) as f:
+        fx = json.load(f)
+    lg = fx["lg_n"]
+    n = 1 << lg
+    d = n - 1
+    words = lambda h: np.array([int(x, 16) for x in h], dtype=np.uint64)
+    c = hal._lib.Context(urs_n=n)
+    try:
+        coeffs, s = orc.rng_scalars(fx["coeff_seed"], fx["deg"] + 1)
+        zw, _ = orc.rng_scalars(s, 2)
+        for name in ("plain", "hiding"):
+            case = fx["cases"][name]
+            w = zw[1] if case["hiding"] else None
+            C = pcdl.commit(c, coeffs, d, w)
+            assert C.tolist() == words(case["C"]).tolist()
+            rng = [fx["open_seed"]]
+            pi = pcdl.open(c, rng, coeffs, C, d, zw[0], w)
+            o = 2 + 24 * lg
+            assert pi[2:14].tolist() == words(case["L0"]).tolist(), "L of the first round"
+            assert pi[2 + 12 * lg: 14 + 12 * lg].tolist() == words(case["R0"]).tolist(), "R of the first round"
+            assert pi[14:26].tolist() == words(case["L1"]).tolist(), "L of the second round (after the two-per-lane fold)"
+            assert pi[2 + 12 * (lg - 1): 2 + 12 * lg].tolist() == words(case["L_last"]).tolist()
+            assert pi[o: o + 12].tolist() == words(case["U"]).tolist() and pi[o + 12: o + 16].tolist() == words(case["c"]).tolist()
+            assert hashlib.sha256(pi.tobytes()).hexdigest() == case["proof_sha256"]
+            assert rng[0] == int(case["rng_state_after"], 16)
+            v = c.poly_eval(coeffs, zw[0])
+            assert v.tolist() == words(case["v"]).tolist()
+            pcdl.check_proof(c, C, d, zw[0], v, pi)
     finally:
         c.close()
 
