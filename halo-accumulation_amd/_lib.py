@@ -82,6 +82,8 @@ _SIGS = {
     "halo_pedersen_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_pcdl_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_pcdl_open": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_pcdl_open_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_pcdl_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_pcdl_succinct_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p]),
     "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_acc_prover": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p, C.c_size_t, u64p]),

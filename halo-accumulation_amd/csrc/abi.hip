@@ -63,7 +63,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipSetDevice(device));
     ctx->device = device;
     ctx->n = n;
-    alloc_epoch_bump();  // device memory is about to be allocated: graphs instantiated before are not replayed (msm.hip)
+    alloc_epoch_bump(ctx);
     for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
     ctx->stream = ctx->streams[0];
     HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 128));
@@ -121,18 +121,62 @@ int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, cons
     return ipa_begin_general(ctx, n, d_coeffs_padded, z, nullptr, nullptr, out);
 }
 // z vector: d_z_vec if given, else z_base^j (times *z_scale if given)
+static void ipa_bufs_free(IpaBuffers &b) {
+    (void)hipFree(b.d_G); (void)hipFree(b.d_c); (void)hipFree(b.d_z);
+    (void)hipFree(b.d_s); (void)hipFree(b.d_s2); (void)hipFree(b.d_FL); (void)hipFree(b.d_FR);
+    (void)hipFree(b.d_pbar);
+    b = IpaBuffers();
+}
+// n x (128 + 32 + 32) bytes of state and four cap_M-element vectors for the no-fold rounds
+static int ipa_bufs_alloc(halo_ctx *ctx, IpaBuffers &b, size_t n, size_t M) {
+    alloc_epoch_bump(ctx);
+    b.cap_n = n;
+    b.cap_M = M;
+    bool ok = hipMalloc(&b.d_G, n * 128) == hipSuccess && hipMalloc(&b.d_c, n * 32) == hipSuccess && hipMalloc(&b.d_z, n * 32) == hipSuccess &&
+              hipMalloc(&b.d_s, M * 32) == hipSuccess && hipMalloc(&b.d_s2, M * 32) == hipSuccess && hipMalloc(&b.d_FL, M * 32) == hipSuccess &&
+              hipMalloc(&b.d_FR, M * 32) == hipSuccess;
+    if (debug_trace()) fprintf(stderr, "[halo] ipa buffers ctx=%p n=%zu M=%zu G=[%p,+%zu) c=%p z=%p\n", (void *)ctx, n, M, (void *)b.d_G, n * 128, (void *)b.d_c, (void *)b.d_z);
+    if (!ok) { ipa_bufs_free(b); set_error("ipa_begin: device allocation failed"); return HALO_E_DEVICE; }
+    return HALO_OK;
+}
+void ipa_bufs_release(halo_ctx *ctx) {
+    if (ctx->ipa_bufs.d_G) alloc_epoch_bump(ctx);
+    ipa_bufs_free(ctx->ipa_bufs);
+}
+
 static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z_base, const host::Fr *z_scale,
                              const uint64_t *d_z_vec, halo_ipa **out) {
     halo_ipa *st = new (std::nothrow) halo_ipa();
     if (!st) { set_error("out of host memory"); return HALO_E_ARG; }
     st->ctx = ctx;
     st->n = st->m = n;
-    alloc_epoch_bump();
     int rc = HALO_OK;
     if (hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) { delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
     do {
-        if (hipMalloc(&st->d_G, n * 128) != hipSuccess || hipMalloc(&st->d_c, n * 32) != hipSuccess ||
-            hipMalloc(&st->d_z, n * 32) != hipSuccess) { set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break; }
+        // The context's own buffers (sized for the whole key on first use) serve one state at a time: the opens of a
+        // prover loop allocate nothing.  A second concurrent state of the same context gets private buffers.
+        size_t M = n < kNoFoldSize ? n : kNoFoldSize;
+        IpaBuffers &cb = ctx->ipa_bufs;
+        IpaBuffers priv;
+        if (!cb.in_use) {
+            size_t want_n = ctx->n > n ? ctx->n : n, want_M = want_n < kNoFoldSize ? want_n : kNoFoldSize;
+            if (want_M < M) want_M = M;
+            if (cb.cap_n < n || cb.cap_M < M) {
+                for (int k = 0; k < HALO_SLOTS; ++k) (void)hipStreamSynchronize(ctx->streams[k]);
+                ipa_bufs_release(ctx);
+                rc = ipa_bufs_alloc(ctx, cb, want_n, want_M);
+                if (rc) break;
+            }
+            cb.in_use = true;
+            st->borrowed = true;
+            priv = cb;
+        } else {
+            rc = ipa_bufs_alloc(ctx, priv, n, M);
+            if (rc) break;
+        }
+        st->d_G = priv.d_G; st->d_c = priv.d_c; st->d_z = priv.d_z;
+        st->d_s = priv.d_s; st->d_s2 = priv.d_s2; st->d_FL = priv.d_FL; st->d_FR = priv.d_FR;
+        st->d_pbar = st->borrowed ? priv.d_pbar : nullptr;
         if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
@@ -146,14 +190,10 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
             if (!rc && z_scale) rc = fr_scale(ctx, st->d_z, n, *z_scale);
         }
         if (rc) break;
-        size_t M = n < kNoFoldSize ? n : kNoFoldSize;
-        if (hipMalloc(&st->d_s, M * 32) != hipSuccess || hipMalloc(&st->d_s2, M * 32) != hipSuccess ||
-            hipMalloc(&st->d_FL, M * 32) != hipSuccess || hipMalloc(&st->d_FR, M * 32) != hipSuccess) {
-            set_error("ipa_begin: device allocation failed"); rc = HALO_E_DEVICE; break;
-        }
         if (n <= kNoFoldSize) rc = ipa_enter_nofold(st);
     } while (0);
     if (rc) { halo_ipa_destroy(st); return rc; }
+    ctx->worker.set_hot(true);
     *out = st;
     return HALO_OK;
 }
@@ -215,9 +255,10 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto st : ctx->streams) if (st) (void)hipStreamSynchronize(st);
     ctx->prof.collect();
+    ctx->worker.stop();
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     msm_workspace_free(ctx);
-    alloc_epoch_bump();
+    ipa_bufs_release(ctx);
     (void)hipFree(ctx->d_bases);
     (void)hipFree(ctx->d_tmp_a);
     (void)hipFree(ctx->d_tmp_b);
@@ -482,7 +523,8 @@ int halo_ipa_dot_cz(halo_ipa *st, uint64_t out[4]) {
     return HALO_OK;
 }
 
-static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp, host::Point *Rp);
+// hterm: if non-null, called as hterm(which, dot) -> dot * H' and added to L (0) / R (1), each on the thread that combines it
+static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp, host::Point *Rp, bool with_hterm = false);
 
 int halo_ipa_round_lr_partial(halo_ipa *st, uint64_t L[12], uint64_t R[12], uint64_t dots_out[8]) {
     if (!st || !L || !R || !dots_out) { set_error("null ipa state"); return HALO_E_ARG; }
@@ -505,16 +547,35 @@ int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], 
     HALO_CTX(ctx);
     host::Fr dots[2];
     host::Point Lp, Rp, Hp = host::Point::load(H_prime);
-    int rc = ipa_round_lr_points(st, dots, &Lp, &Rp);
+    if (!st->hp_from_scalar && !st->hp_table.matches(Hp)) st->hp_table = host::FixedBaseTable(Hp);  // H' is fixed for a whole open
+    int rc = ipa_round_lr_points(st, dots, &Lp, &Rp, true);  // L, R come back with their H' terms, normalised
     if (rc) return rc;
-    if (!st->hp_table.matches(Hp)) st->hp_table = host::FixedBaseTable(Hp);  // H' is fixed for a whole open
-    (Lp + st->hp_table.mul(dots[0])).store_normalized(L);
-    (Rp + st->hp_table.mul(dots[1])).store_normalized(R);
+    Lp.store(L);
+    Rp.store(R);
     return HALO_OK;
 }
 
+} // extern "C"
+namespace halo {
+const host::FixedBaseTable &public_h_table() {
+    static const host::FixedBaseTable tbl = [] {
+        uint64_t S[12], H[12];
+        halo_public_points(S, H);
+        return host::FixedBaseTable(host::Point::load(H));
+    }();
+    return tbl;
+}
+void ipa_set_hprime_scalar(halo_ipa *st, const host::Fr &xi0) {
+    st->hp_from_scalar = true;
+    st->hp_scalar = xi0;
+    (void)public_h_table();
+}
+}  // namespace halo
+extern "C" {
+
+
 // <c_r, G_l>, <c_l, G_r> and the two dot products of one round, without the H' terms
-static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_out, host::Point *Rp_out) {
+static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_out, host::Point *Rp_out, bool with_hterm) {
     halo_ctx *ctx = st->ctx;
     if (st->m < 2) { set_error("ipa_round_lr: no rounds left"); return HALO_E_ARG; }
     size_t m = st->m / 2;
@@ -544,11 +605,27 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     ctx->stream = ctx->streams[2];
     int rcd = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
     ctx->stream = saved;
-    rc = msm_finish(ctx, 0, &Lp);
-    int rc2 = msm_finish(ctx, 1, &Rp);
-    if (rc) return rc;
-    if (rc2) return rc2;
-    if (rcd) return rcd;
+    rc = msm_wait(ctx, 0, 1);
+    int rc2 = msm_wait(ctx, 1, 1);
+    if (rc || rc2 || rcd) {
+        if (!rc2 && rc) { /* slot 1 was waited for: nothing left in flight */ }
+        return rc ? rc : (rc2 ? rc2 : rcd);
+    }
+    // Window combine (~250 doublings each), the H' term and the normalisation of R on the helper thread while this
+    // thread does L's: pure host arithmetic on both sides.
+    auto finish_one = [st, ctx, with_hterm](int slot, const host::Fr &dot, host::Point *out) {
+        host::Point p;
+        msm_combine(ctx, slot, &p, 1);
+        if (with_hterm) {
+            p = p + (st->hp_from_scalar ? public_h_table().mul(dot * st->hp_scalar) : st->hp_table.mul(dot));
+            p = p.normalized();
+        }
+        *out = p;
+    };
+    host::Fr dl = dots[0], dr = dots[1];
+    ctx->worker.submit([&finish_one, &Rp, dr] { finish_one(1, dr, &Rp); });
+    finish_one(0, dl, &Lp);
+    ctx->worker.wait();
     *Lp_out = Lp;
     *Rp_out = Rp;
     return HALO_OK;
@@ -610,9 +687,14 @@ int halo_ipa_hiding_partial(halo_ipa *st, uint64_t rng_state, size_t deg, const 
     HALO_CTX(ctx);
     if (st->m != st->n) { set_error("ipa_hiding_partial: rounds already started"); return HALO_E_ARG; }
     if (deg == 0) { set_error("open: hiding needs p.degree() >= 1"); return HALO_E_ASSERT; }
-    if (!st->d_pbar && hipMalloc(&st->d_pbar, st->n * 32) != hipSuccess) { set_error("ipa_hiding_partial: allocation failed"); return HALO_E_DEVICE; }
+    if (!st->d_pbar) {
+        alloc_epoch_bump(ctx);
+        size_t cap = st->borrowed ? ctx->ipa_bufs.cap_n : st->n;
+        if (hipMalloc(&st->d_pbar, cap * 32) != hipSuccess) { set_error("ipa_hiding_partial: allocation failed"); return HALO_E_DEVICE; }
+    }
     int rc = pbar_stream_dev(ctx, rng_state, deg, host::Fr::load(z), stride, offset, st->n, st->d_pbar);
     if (rc) return rc;
+    st->pbar_valid = true;
     host::Point part;
     rc = msm_run(ctx, st->d_G, st->d_pbar, true, st->n, &part);
     if (rc) return rc;
@@ -621,7 +703,7 @@ int halo_ipa_hiding_partial(halo_ipa *st, uint64_t rng_state, size_t deg, const 
 }
 // p' = p + alpha p_bar on this shard (pcdl.rs:156)
 int halo_ipa_apply_hiding(halo_ipa *st, const uint64_t alpha[4]) {
-    if (!st || !alpha || !st->d_pbar) { set_error("ipa_apply_hiding: no p_bar on this state"); return HALO_E_ARG; }
+    if (!st || !alpha || !st->d_pbar || !st->pbar_valid) { set_error("ipa_apply_hiding: no p_bar on this state"); return HALO_E_ARG; }
     halo_ctx *ctx = st->ctx;
     HALO_CTX(ctx);
     if (st->m != st->n) { set_error("ipa_apply_hiding: rounds already started"); return HALO_E_ARG; }
@@ -637,17 +719,23 @@ int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4
 
 void halo_ipa_destroy(halo_ipa *st) {
     if (!st) return;
-    alloc_epoch_bump();
-    if (st->ctx) {
-        (void)hipSetDevice(st->ctx->device);
-        (void)hipStreamSynchronize(st->ctx->stream);
+    halo_ctx *ctx = st->ctx;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->streams[k]);  // folds, the second MSM, the dot products
     }
-    if (st->ctx) (void)hipStreamSynchronize(st->ctx->streams[1]);
-    (void)hipFree(st->d_G);
-    (void)hipFree(st->d_c);
-    (void)hipFree(st->d_z);
-    (void)hipFree(st->d_s); (void)hipFree(st->d_s2); (void)hipFree(st->d_FL); (void)hipFree(st->d_FR);
-    (void)hipFree(st->d_pbar);
+    if (ctx) ctx->worker.set_hot(false);
+    if (st->borrowed && ctx) {
+        ctx->ipa_bufs.d_pbar = st->d_pbar;  // lazily allocated by the hiding branch of a sharded open: kept with the rest
+        ctx->ipa_bufs.in_use = false;
+    } else if (st->d_G) {
+        if (ctx) alloc_epoch_bump(ctx);
+        (void)hipFree(st->d_G);
+        (void)hipFree(st->d_c);
+        (void)hipFree(st->d_z);
+        (void)hipFree(st->d_s); (void)hipFree(st->d_s2); (void)hipFree(st->d_FL); (void)hipFree(st->d_FR);
+        (void)hipFree(st->d_pbar);
+    }
     if (st->ev) (void)hipEventDestroy(st->ev);
     delete st;
 }

@@ -2,10 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/halo_accumulation.h"
@@ -105,13 +110,82 @@ struct MsmWorkspace {
     };
     GraphKey seen_key, graph_key;
     hipGraphExec_t graph_exec = nullptr;
-    uint64_t graph_epoch = 0;  // alloc_epoch() when graph_exec was instantiated
+    uint64_t graph_epoch = 0;  // the context's alloc_epoch when graph_exec was instantiated
     MsmPlan graph_plan{};
 };
 
 }  // namespace halo
 
 constexpr int HALO_SLOTS = 4;
+
+namespace halo {
+// One helper thread per context for pure host arithmetic that would otherwise serialise on the caller's thread
+// (the window combine of the second MSM of an IPA round while the caller combines the first).  It never touches
+// HIP.  While `hot` (an IPA state is alive) it polls for work instead of sleeping: a round arrives every few
+// hundred microseconds and a condition-variable wake-up would cost a good part of what the overlap saves.
+class HostWorker {
+   public:
+    ~HostWorker() { stop(); }
+    void submit(std::function<void()> fn) {
+        start();
+        job_ = std::move(fn);
+        done_.store(false, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(mu_); pending_.store(true, std::memory_order_release); }
+        cv_.notify_one();
+    }
+    void wait() {
+        if (!thread_.joinable()) return;
+        while (!done_.load(std::memory_order_acquire)) std::this_thread::yield();
+    }
+    void set_hot(bool hot) {
+        hot_.store(hot, std::memory_order_relaxed);
+        if (hot) { start(); cv_.notify_one(); }
+    }
+    void stop() {
+        if (!thread_.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu_); quit_.store(true); }
+        cv_.notify_one();
+        thread_.join();
+    }
+
+   private:
+    void start() {
+        if (thread_.joinable()) return;
+        done_.store(true);
+        thread_ = std::thread([this] { loop(); });
+    }
+    void loop() {
+        for (;;) {
+            if (!pending_.load(std::memory_order_acquire)) {
+                if (quit_.load()) return;
+                if (hot_.load(std::memory_order_relaxed)) { std::this_thread::yield(); continue; }
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return pending_.load() || quit_.load() || hot_.load(); });
+                continue;
+            }
+            pending_.store(false, std::memory_order_relaxed);
+            job_();
+            done_.store(true, std::memory_order_release);
+        }
+    }
+    std::thread thread_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    std::atomic<bool> pending_{false}, done_{true}, quit_{false}, hot_{false};
+};
+}  // namespace halo
+
+// Device buffers of one pcdl::open (pcdl.rs:183-186 state + the no-fold vectors), owned by the context and reused
+// from open to open: the open path performs no device allocation after the first call.
+struct IpaBuffers {
+    uint32_t *d_G = nullptr;                                       // cap_n x 32 words (native affine, 128-B stride)
+    uint64_t *d_c = nullptr, *d_z = nullptr;                       // cap_n x 4
+    uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // cap_M x 4
+    uint64_t *d_pbar = nullptr;                                    // cap_n x 4, hiding branch of a sharded open (lazy)
+    size_t cap_n = 0, cap_M = 0;
+    bool in_use = false;
+};
 
 struct halo_ctx {
     int device = 0;
@@ -133,6 +207,9 @@ struct halo_ctx {
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
     // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover
     uint64_t *d_poly = nullptr, *d_poly2 = nullptr;
+    halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker)
+    IpaBuffers ipa_bufs;          // reused by every halo_ipa of this context (one at a time; a second one allocates its own)
+    uint64_t alloc_epoch = 0;     // bumped whenever this context allocates or frees device memory (see msm.hip, launch graphs)
 };
 
 struct halo_ipa {
@@ -142,25 +219,32 @@ struct halo_ipa {
     uint64_t *d_c = nullptr;  // m x 4
     uint64_t *d_z = nullptr;  // m x 4
     halo::host::FixedBaseTable hp_table;  // window table of the H' this open uses (pcdl.rs:181)
+    bool hp_from_scalar = false;          // H' = hp_scalar * H: terms k * H' come from the process-wide table of H as (k * hp_scalar) * H
+    halo::host::Fr hp_scalar;
     hipEvent_t ev = nullptr;  // orders slot 1's stream after the folds queued on stream 0
     // no-fold mode (ipa.hip): G stays at M points, s holds the challenge products
     bool nofold = false;
     size_t M = 0, s_len = 0;
     uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
     uint64_t *d_pbar = nullptr;  // n x 4: this shard of p_bar (hiding branch of the sharded open)
+    bool pbar_valid = false;     // halo_ipa_hiding_partial has filled d_pbar for this state
+    bool borrowed = false;       // buffers belong to ctx->ipa_bufs (returned, not freed, by halo_ipa_destroy)
 };
 
 namespace halo {
 
 // ---- msm.hip
-// counts the (de)allocations of device memory by this library (all contexts of the process)
-uint64_t alloc_epoch();
-void alloc_epoch_bump();
+// a context's count of its own device (de)allocations
+inline void alloc_epoch_bump(halo_ctx *ctx) { ctx->alloc_epoch++; }
 int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);
 void msm_workspace_free(halo_ctx *ctx);
 // asynchronous halves of msm_run on workspace/stream `slot`
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n);
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out);
+// the two halves of msm_finish: wait for the slot's launches (HIP), then combine the window sums (pure host arithmetic,
+// may run on another thread); batch as msm_finish_batch
+int msm_wait(halo_ctx *ctx, int slot, int count);
+void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count);
 // the same for `members.count` MSMs of n points each issued as ONE launch sequence; out[count]
 int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const MsmBatch &members, bool scalars_mont, size_t n);
 int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count);
@@ -197,6 +281,10 @@ int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_
 int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out);
 
 // ---- abi.hip (device-pointer forms used by pcdl_acc.hip)
+// H' = xi0 * H for this state (pcdl.rs:181): lets the rounds use the process-wide window table of H
+void ipa_set_hprime_scalar(halo_ipa *st, const host::Fr &xi0);
+// process-wide window table of the public point H (consts.rs:45-65), built on first use
+const host::FixedBaseTable &public_h_table();
 int ipa_begin_dev(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_padded, const host::Fr &z, halo_ipa **out);
 int upload_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words);
 int download_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words);

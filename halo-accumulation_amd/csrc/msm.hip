@@ -885,12 +885,7 @@ static size_t max_counts() { return (size_t)16 * 32768; }  // c = 16 is the larg
 struct WorkspaceNeed {
     size_t n, counts, sorted, tasks, hist, windows;
 };
-static std::atomic<uint64_t> g_alloc_epoch{0};
-uint64_t alloc_epoch() { return g_alloc_epoch.load(std::memory_order_relaxed); }
-void alloc_epoch_bump() { g_alloc_epoch.fetch_add(1, std::memory_order_relaxed); }
-
 static void workspace_release(MsmWorkspace &ws) {
-    alloc_epoch_bump();
     if (debug_trace()) fprintf(stderr, "[halo] workspace release %p (graph %p)\n", (void *)&ws, (void *)ws.graph_exec);
     uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
     uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_presort, ws.d_ntask, ws.d_toff,
@@ -902,7 +897,6 @@ static void workspace_release(MsmWorkspace &ws) {
     ws = MsmWorkspace();
 }
 static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
-    alloc_epoch_bump();
     ws.cap_n = need.n;
     ws.cap_counts = need.counts;
     ws.cap_sorted = need.sorted;
@@ -949,9 +943,11 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     }
     need.hist = (size_t)256 * 32768 + need.counts;  // W * nchunks <= 256 blocks of B <= 32768 counters
     need.windows = 64;
+    alloc_epoch_bump(ctx);
     return workspace_alloc(ctx->wss[slot], need);
 }
 void msm_workspace_free(halo_ctx *ctx) {
+    alloc_epoch_bump(ctx);
     for (int slot = 0; slot < HALO_SLOTS; ++slot) workspace_release(ctx->wss[slot]);
 }
 
@@ -1024,6 +1020,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         }
         WorkspaceNeed need;
         if ((members.count > 1 || ctx->task_len > 0) && batch_need(ctx, ws, n, members.count, need)) {
+            alloc_epoch_bump(ctx);
             workspace_release(ws);
             int rc = workspace_alloc(ws, need);
             if (rc) return rc;
@@ -1043,7 +1040,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     // buffer and getting the same address back for a new one -- ended in a GPU memory fault on ROCm 7.2
     // (tests/test_gpu_parity.py: pipelined slots -> randomised configurations -> batch_2_18, in that order).
     // Callers must keep the scalar buffers of a repeated launch allocated between the repetitions.
-    if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != alloc_epoch())) {
+    if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != ctx->alloc_epoch)) {
         (void)hipGraphExecDestroy(ws.graph_exec);
         ws.graph_exec = nullptr;
         ws.graph_key = MsmWorkspace::GraphKey();
@@ -1071,7 +1068,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         if (e != hipSuccess) { ws.graph_exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
         ws.graph_key = key;
         ws.graph_plan = ws.plan;
-        ws.graph_epoch = alloc_epoch();
+        ws.graph_epoch = ctx->alloc_epoch;
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
     }
     if (rc) return rc;
@@ -1185,18 +1182,24 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
 
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out) { return msm_finish_batch(ctx, slot, out, 1); }
 
-int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {
-    for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
+int msm_wait(halo_ctx *ctx, int slot, int count) {
     if (slot < 0 || slot >= HALO_SLOTS || !ctx->wss[slot].in_flight) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
     MsmWorkspace &ws = ctx->wss[slot];
-    MsmPlan p = ws.plan;
-    if (p.batch != count) { set_error("msm: this slot holds a batch of a different size"); return HALO_E_ARG; }
+    if (ws.plan.batch != count) { set_error("msm: this slot holds a batch of a different size"); return HALO_E_ARG; }
     ws.in_flight = false;
-    if (p.W == 0) return HALO_OK;  // n == 0, or a window shard without windows
+    if (ws.plan.W == 0) return HALO_OK;  // n == 0, or a window shard without windows
     HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
     bool others = false;
     for (int k = 0; k < HALO_SLOTS; ++k) others = others || ctx->wss[k].in_flight;
     if (ctx->prof.on && !others) ctx->prof.collect();
+    return HALO_OK;
+}
+// Horner over the window sums the slot's last launch left in pinned memory (call after msm_wait)
+void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
+    const MsmWorkspace &ws = ctx->wss[slot];
+    MsmPlan p = ws.plan;
+    for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
+    if (p.W == 0) return;
     int Wm = p.w1 - p.w0;
     for (int b = 0; b < count; ++b) {
         host::Point acc = host::Point::infinity();
@@ -1209,6 +1212,12 @@ int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {
             for (int k = 0; k < p.c * p.w0; ++k) acc = acc.dbl();  // a window shard's weight 2^(c * w0)
         out[b] = acc;
     }
+}
+int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {
+    for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
+    int rc = msm_wait(ctx, slot, count);
+    if (rc) return rc;
+    msm_combine(ctx, slot, out, count);
     return HALO_OK;
 }
 

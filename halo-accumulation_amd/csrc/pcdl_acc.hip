@@ -55,6 +55,7 @@ static Fr rho0_xi_L_R(const Fr &xi, const Point &L, const Point &R) {
 
 static int ensure_poly_buffers(halo_ctx *ctx) {
     size_t n = ctx->n < 64 ? 64 : ctx->n;
+    if (!ctx->d_poly || !ctx->d_poly2) alloc_epoch_bump(ctx);
     if (!ctx->d_poly) HALO_HIP(hipMalloc(&ctx->d_poly, n * 32));
     if (!ctx->d_poly2) HALO_HIP(hipMalloc(&ctx->d_poly2, n * 32));
     return HALO_OK;
@@ -151,6 +152,7 @@ static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point 
     rc = ipa_begin_dev(ctx, n, ctx->d_poly, z, &st);  // :183-186
     if (rc) return rc;
     std::unique_ptr<halo_ipa, void (*)(halo_ipa *)> guard(st, halo_ipa_destroy);
+    ipa_set_hprime_scalar(st, xi);  // H' = xi_0 H: the rounds take k H' = (k xi_0) H from the process-wide table of H
     for (size_t round = 0; round < lg_n; ++round) {
         uint64_t *Lw = pf_L(proof, round), *Rw = pf_R(proof, lg_n, round);
         rc = halo_ipa_round_lr(st, Hp_w, Lw, Rw);  // :203-208
@@ -179,9 +181,16 @@ static bool proof_wellformed(uint64_t *proof, size_t lg_n) {
     return true;
 }
 
-// pcdl.rs:252-314.  The 2 lg n + O(1) scalar multiplications are one interleaved host MSM.
-static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c,
-                               std::vector<Fr> *xis_out, Point *U_out) {
+// pcdl.rs:252-314 in two halves.  challenges(): everything the transcript decides -- C', xi_0 .. xi_lg (pcdl.rs:272-296);
+// this is all pcdl::check's linear-time half (h.get_poly + the MSM, pcdl.rs:338) needs, so that half is launched
+// before relation() runs on the host.  relation(): the 2 lg n + O(1) scalar multiplications as one interleaved
+// host MSM and the final comparison (pcdl.rs:288-310).
+struct SuccinctState {
+    size_t lg_n = 0;
+    Point C_prime, Hp, U;
+    std::vector<Fr> xis;
+};
+static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c, SuccinctState *st) {
     uint64_t *proof = const_cast<uint64_t *>(proof_c);
     size_t n = d + 1;
     if (!is_pow2(n)) return fail_reject("d+1 is not a power of 2!");
@@ -193,26 +202,35 @@ static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr
     if (!C.on_curve() || !scalar_ok(z) || !scalar_ok(v)) return fail_reject("instance holds an invalid point or scalar");
     if (!proof_wellformed(proof, lg_n)) return fail_reject("proof holds an invalid point or scalar");
     const PublicPoints &pp = public_points();
-    Point C_prime = C;
+    st->lg_n = lg_n;
+    st->C_prime = C;
     if (proof[0]) {
         Point C_bar = Point::load(pf_Cbar(proof, lg_n));
         Fr wp = Fr::load(pf_wp(proof, lg_n));
         Fr a = rho0_C_z_v_Cbar(C, z, v, C_bar);
-        C_prime = C + C_bar.mul(a) - pp.S.mul(wp);
+        st->C_prime = C + C_bar.mul(a) - pp.S.mul(wp);
     }
-    std::vector<Fr> xis(lg_n + 1);
-    xis[0] = rho0_C_z_v(C_prime, z, v);
-    Point Hp = pp.H.mul(xis[0]);
+    st->xis.assign(lg_n + 1, Fr::zero());
+    st->xis[0] = rho0_C_z_v(st->C_prime, z, v);
+    st->Hp = pp.H.mul(st->xis[0]);
+    for (size_t i = 0; i < lg_n; ++i) {
+        st->xis[i + 1] = rho0_xi_L_R(st->xis[i], Point::load(pf_L(proof, i)), Point::load(pf_R(proof, lg_n, i)));
+        if (st->xis[i + 1].is_zero()) return fail_reject("challenge is zero");
+    }
+    st->U = Point::load(pf_U(proof, lg_n));
+    return HALO_OK;
+}
+static int succinct_relation(const SuccinctState &st, const Fr &z, const Fr &v, const uint64_t *proof_c) {
+    uint64_t *proof = const_cast<uint64_t *>(proof_c);
+    size_t lg_n = st.lg_n;
+    const std::vector<Fr> &xis = st.xis;
     std::vector<Point> pts;
     std::vector<Fr> ks;
     pts.reserve(2 * lg_n + 1);
     ks.reserve(2 * lg_n + 1);
     for (size_t i = 0; i < lg_n; ++i) {
-        Point L = Point::load(pf_L(proof, i)), R = Point::load(pf_R(proof, lg_n, i));
-        xis[i + 1] = rho0_xi_L_R(xis[i], L, R);
-        if (xis[i + 1].is_zero()) return fail_reject("challenge is zero");
-        pts.push_back(L); ks.push_back(xis[i + 1]);  // scalar replaced by its inverse below
-        pts.push_back(R); ks.push_back(xis[i + 1]);
+        pts.push_back(Point::load(pf_L(proof, i))); ks.push_back(xis[i + 1]);  // scalar replaced by its inverse below
+        pts.push_back(Point::load(pf_R(proof, lg_n, i))); ks.push_back(xis[i + 1]);
     }
     // one inversion for all challenges (Montgomery's trick)
     {
@@ -224,35 +242,47 @@ static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr
             inv = inv * xis[i + 1];
         }
     }
-    pts.push_back(Hp); ks.push_back(v);
-    Point C_i = C_prime + host::small_msm(pts, ks);  // :288-298
+    pts.push_back(st.Hp); ks.push_back(v);
+    Point C_i = st.C_prime + host::small_msm(pts, ks);  // :288-298
     // :301-304  v' = c * h(z)
     Fr c = Fr::load(pf_c(proof, lg_n));
     Fr hz = Fr::one() + xis[lg_n] * z, zi = z;
     for (size_t i = 1; i < lg_n; ++i) { zi = zi.sqr(); hz = hz * (Fr::one() + xis[lg_n - i] * zi); }
     Fr v_prime = c * hz;
-    Point U = Point::load(pf_U(proof, lg_n));
-    std::vector<Point> p2{U, Hp};
+    std::vector<Point> p2{st.U, st.Hp};
     std::vector<Fr> k2{c, v_prime};
     if (C_i != host::small_msm(p2, k2)) return fail_reject("C_(log_n) != CM.Commit_Sigma(c || v')");  // :307-310
-    *xis_out = std::move(xis);
-    *U_out = U;
+    return HALO_OK;
+}
+static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c,
+                               std::vector<Fr> *xis_out, Point *U_out) {
+    SuccinctState st;
+    int rc = succinct_challenges(ctx, C, d, z, v, proof_c, &st);
+    if (!rc) rc = succinct_relation(st, z, v, proof_c);
+    if (rc) return rc;
+    *xis_out = std::move(st.xis);
+    *U_out = st.U;
     return HALO_OK;
 }
 
-// pcdl.rs:323-342
+// pcdl.rs:323-342.  The device half (h coefficients + the n-point MSM, :338) runs while the host evaluates the
+// succinct relation; errors are reported in the reference's order (succinct check first).
 static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof) {
-    std::vector<Fr> xis;
-    Point U;
-    int rc = succinct_check_host(ctx, C, d, z, v, proof, &xis, &U);
+    SuccinctState st;
+    int rc = succinct_challenges(ctx, C, d, z, v, proof, &st);
     if (rc) return rc;
-    size_t lg_n = ilog2(d + 1), n = d + 1;
-    rc = h_coeffs_dev(ctx, xis.data(), lg_n, Fr::one(), false, ctx->d_tmp_a);  // h.get_poly().coeffs
+    size_t lg_n = st.lg_n, n = d + 1;
+    rc = h_coeffs_dev(ctx, st.xis.data(), lg_n, Fr::one(), false, ctx->d_tmp_a);  // h.get_poly().coeffs
     if (rc) return rc;
+    rc = msm_enqueue(ctx, 0, ctx->d_bases, ctx->d_tmp_a, true, n);  // :338, asynchronous
+    if (rc) return rc;
+    int rc_rel = succinct_relation(st, z, v, proof);
+    std::string rel_err = rc_rel ? halo_last_error() : "";
     Point comm;
-    rc = msm_run(ctx, ctx->d_bases, ctx->d_tmp_a, true, n, &comm);  // :338
+    rc = msm_finish(ctx, 0, &comm);
+    if (rc_rel) { set_error(rel_err); return rc_rel; }
     if (rc) return rc;
-    if (U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339
+    if (st.U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339
     return HALO_OK;
 }
 
@@ -408,6 +438,45 @@ int halo_pcdl_open(halo_ctx *ctx, uint64_t *rng_state, const uint64_t *coeffs, s
     rc = pcdl_open_dev(ctx, &rng, deg, Point::load(C), d, Fr::load(z), w ? &wf : nullptr, proof_out);
     if (rng_state) *rng_state = rng.state;
     return rc;
+}
+
+// pcdl::open for a polynomial that already lives in device memory (the coefficients are copied, not clobbered)
+int halo_pcdl_open_dev(halo_ctx *ctx, uint64_t *rng_state, const void *d_coeffs, size_t len, const uint64_t C[12], size_t d,
+                       const uint64_t z[4], const uint64_t *w, uint64_t *proof_out) {
+    HALO_CTX2(ctx);
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_assert("open: d + 1 is not a power of two");  // pcdl.rs:130
+    if (len == 0 || !d_coeffs || !C || !z || !proof_out) { set_error("open_dev: null pointer or empty polynomial"); return HALO_E_ARG; }
+    if (len - 1 > d) return fail_assert("open: p.degree() > d");                // pcdl.rs:131
+    if (n > ctx->n) return fail_assert("open: d > D");                          // pcdl.rs:132
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    HALO_HIP(hipMemcpyAsync(ctx->d_poly, d_coeffs, len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    if (len < n) HALO_HIP(hipMemsetAsync(ctx->d_poly + 4 * len, 0, (n - len) * 32, ctx->stream));
+    host::Rng rng{rng_state ? *rng_state : 0};
+    Fr wf = w ? Fr::load(w) : Fr::zero();
+    rc = pcdl_open_dev(ctx, &rng, len - 1, Point::load(C), d, Fr::load(z), w ? &wf : nullptr, proof_out);
+    if (rng_state) *rng_state = rng.state;
+    return rc;
+}
+// pcdl::commit for device-resident coefficients (len <= d + 1)
+int halo_pcdl_commit_dev(halo_ctx *ctx, const void *d_coeffs, size_t len, size_t d, const uint64_t *w, uint64_t out[12]) {
+    HALO_CTX2(ctx);
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_assert("commit: d + 1 is not a power of two");
+    if (!out || (len && !d_coeffs)) { set_error("commit_dev: null pointer"); return HALO_E_ARG; }
+    if (len > n) return fail_assert("commit: p.degree() > d");
+    if (n > ctx->n) return fail_assert("commit: d > D");
+    int rc = ensure_poly_buffers(ctx);
+    if (rc) return rc;
+    if (len) HALO_HIP(hipMemcpyAsync(ctx->d_poly2, d_coeffs, len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    if (len < n) HALO_HIP(hipMemsetAsync(ctx->d_poly2 + 4 * len, 0, (n - len) * 32, ctx->stream));
+    Fr wf = w ? Fr::load(w) : Fr::zero();
+    Point r;
+    rc = pedersen_commit_dev(ctx, w ? &wf : nullptr, ctx->d_poly2, n, &r);
+    if (rc) return rc;
+    r.store_normalized(out);
+    return HALO_OK;
 }
 
 int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],

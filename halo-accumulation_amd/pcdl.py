@@ -38,6 +38,22 @@ def open(ctx, rng, p, Cm, d, z, w=None):
     return proof
 
 
+def commit_dev(ctx, dptr, length, d, w=None):
+    """pcdl::commit for `length` coefficients resident in device memory"""
+    out = np.zeros(12, dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_commit_dev(ctx.h, C.c_void_p(dptr), length, d, ptr(_a(w)), ptr(out)))
+    return out
+
+
+def open_dev(ctx, rng, dptr, length, Cm, d, z, w=None):
+    """pcdl::open for a polynomial resident in device memory (length = degree + 1) -> EvalProof blob"""
+    st = C.c_uint64(rng[0])
+    proof = np.zeros(ctx.lib.halo_proof_words(max(lg_of(d), 0)), dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_open_dev(ctx.h, C.byref(st), C.c_void_p(dptr), length, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(w)), ptr(proof)))
+    rng[0] = st.value
+    return proof
+
+
 def succinct_check(ctx, Cm, d, z, v, pi):
     """pcdl.rs:252-314 -> (xis of h, U); raises HaloReject where the reference returns Err"""
     lg = max(lg_of(d), 0)

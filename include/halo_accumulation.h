@@ -170,6 +170,12 @@ int halo_pcdl_commit(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d
 /* pcdl::open (pcdl.rs:120-242) */
 int halo_pcdl_open(halo_ctx *ctx, uint64_t *rng_state, const uint64_t *coeffs, size_t len, const uint64_t C[12], size_t d,
                    const uint64_t z[4], const uint64_t *w /*nullable*/, uint64_t *proof_out);
+/* The same two for a polynomial already resident in device memory (len x 4 limbs, Montgomery; len = p.degree() + 1,
+ * i.e. the top coefficient is non-zero as ark-poly's DensePolynomial guarantees).  The coefficients are read, not
+ * modified.  No host-to-device transfer of the polynomial: this is the form whose rate bench.py reports. */
+int halo_pcdl_commit_dev(halo_ctx *ctx, const void *d_coeffs, size_t len, size_t d, const uint64_t *w /*nullable*/, uint64_t out[12]);
+int halo_pcdl_open_dev(halo_ctx *ctx, uint64_t *rng_state, const void *d_coeffs, size_t len, const uint64_t C[12], size_t d,
+                       const uint64_t z[4], const uint64_t *w /*nullable*/, uint64_t *proof_out);
 /* pcdl::succinct_check (pcdl.rs:252-314): xis_out (lg+1) x 4, U_out */
 int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
                              const uint64_t *proof, uint64_t *xis_out, uint64_t U_out[12]);
