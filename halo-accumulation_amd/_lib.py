@@ -101,6 +101,7 @@ _SIGS = {
     "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -319,6 +320,9 @@ class Context:
 
     def set_sort_mode(self, mode):
         check(self.lib.halo_set_sort_mode(self.h, mode))
+
+    def set_small_path(self, mode):
+        check(self.lib.halo_set_small_path(self.h, mode))
 
     def set_task_len(self, n):
         check(self.lib.halo_set_task_len(self.h, n))

@@ -889,6 +889,11 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode) {
     ctx->sort_two_level = mode;
     return HALO_OK;
 }
+int halo_set_small_path(halo_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
+    ctx->small_path = mode;
+    return HALO_OK;
+}
 int halo_set_task_len(halo_ctx *ctx, int len) {
     if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }
     ctx->task_len = len;
@@ -909,9 +914,9 @@ int halo_test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *a, cons
 int halo_test_point_op(halo_ctx *ctx, int op, const uint64_t *a_jac, const uint64_t *b, size_t n, uint64_t *out_jac) {
     HALO_CTX(ctx);
     if (n > (ctx->n < 64 ? 64 : ctx->n) / 2) { set_error("test_point_op: n exceeds half the context size"); return HALO_E_ARG; }
-    size_t bw = op == 0 ? 12 : (op == 1 ? 8 : 4);
+    size_t bw = (op == 0 || op == 4 || op == 6) ? 12 : (op == 1 ? 8 : 4);
     int rc = upload(ctx, ctx->d_tmp_a, a_jac, n * 12);
-    if (!rc && b && op != 2) rc = upload(ctx, ctx->d_tmp_b, b, n * bw);
+    if (!rc && b && op != 2 && op != 5) rc = upload(ctx, ctx->d_tmp_b, b, n * bw);
     if (rc) return rc;
     // output goes to the upper half of d_tmp_a? keep it simple: a dedicated allocation
     uint64_t *d_out = nullptr;

@@ -199,6 +199,7 @@ struct halo_ctx {
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
     int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^17), 0 never, 1 whenever the shape allows
     int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
+    int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
     // scratch for host-pointer entry points
@@ -257,6 +258,11 @@ int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t 
 int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+
+// ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
+int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
+                 uint32_t kmax);
+int smsm_prepare();
 
 // ---- ipa.hip
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont);

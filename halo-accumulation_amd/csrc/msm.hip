@@ -19,9 +19,10 @@
 // msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
 // overlap on the context's slots (workspace + stream each).
 #include <atomic>
+#include <cstring>
 #include <thread>
 
-#include "curve.cuh"
+#include "curve_quad.cuh"
 #include "internal.hpp"
 
 namespace halo {
@@ -36,6 +37,19 @@ MsmPlan msm_plan(size_t n, int forced_c) {
     // bits (c = 14, 12, 11, 9) are avoided: that window puts n/4 points into each of ~4 buckets.
     static const int table[] = {/*lg 10*/ 8, 8, 8, 10, 10, 13, 13, 15, 15, /*lg 19*/ 15};
     int c = forced_c > 0 ? forced_c : (lg >= 20 ? 16 : lg >= 10 ? table[lg - 10] : lg - 2);
+    // development override, e.g. HALO_PLAN="16:12,15:12": window bits for MSMs of 2^lg <= n < 2^(lg+1) points
+    static const char *plan_env = getenv("HALO_PLAN");
+    if (plan_env && forced_c <= 0) {
+        for (const char *q = plan_env; *q;) {
+            int l = atoi(q);
+            const char *colon = strchr(q, ':');
+            if (!colon) break;
+            if (l == lg) c = atoi(colon + 1);
+            const char *comma = strchr(colon, ',');
+            if (!comma) break;
+            q = comma + 1;
+        }
+    }
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     MsmPlan p;
@@ -780,6 +794,21 @@ __global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, c
     }
 }
 
+// the quad-parallel forms of curve_quad.cuh, one point per 4 lanes: op 4 = a + b (XYZZ add), op 5 = 2a, op 6 = a + b where
+// every fourth pair is replaced by (a, a) so that general additions and doublings share a wave
+__global__ __launch_bounds__(256) void k_test_point_quad(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t i = t >> 2;
+    int ql = (int)(t & 3);
+    bool live = i < n;
+    if (!live) i = n - 1;  // keep every lane of the wave busy: the quad forms need whole quads
+    XyzzN x = jac_to_xyzz(jac_from_words(a + 12 * (size_t)i));
+    XyzzN y = jac_to_xyzz(jac_from_words((op == 5 || (op == 6 && (i & 3) == 3) ? a : b) + 12 * (size_t)i));
+    if (op == 5) x = xyzz_dbl_quad(x, ql);
+    else xyzz_add_quad(x, y, ql);
+    if (live && ql == 0) xyzz_store_jac_words(out + 12 * (size_t)i, x);
+}
+
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (field == 2) HALO_LAUNCH(ctx, "k_test_field29", k_test_field29, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
@@ -790,6 +819,11 @@ int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const u
 }
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (op >= 4) {
+        HALO_LAUNCH(ctx, "k_test_point_quad", k_test_point_quad, dim3((unsigned)((4 * n + 255) / 256)), block, 0, op, d_a, d_b, (uint32_t)n, d_out);
+        HALO_HIP(hipGetLastError());
+        return HALO_OK;
+    }
     HALO_LAUNCH(ctx, "k_test_point", k_test_point, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
@@ -908,6 +942,7 @@ static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
+    { int rc = smsm_prepare(); if (rc) return rc; }
     HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
     HALO_HIP(hipMalloc(&ws.d_hist, ws.cap_hist * 4));          // [w][chunk][b]
     HALO_HIP(hipMalloc(&ws.d_counts, ws.cap_counts * 4));
@@ -967,7 +1002,12 @@ struct StreamGuard {  // the launch macro uses ctx->stream
     ~StreamGuard() { ctx->stream = saved; }
 };
 
-static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) { return ctx->task_len > 0 ? (uint32_t)ctx->task_len : n >= ((size_t)1 << 18) ? KMAX : 16u; }
+static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) {
+    static const int small_env = getenv("HALO_SMSM_KMAX") ? atoi(getenv("HALO_SMSM_KMAX")) : 0;  // development override
+    if (ctx->task_len > 0) return (uint32_t)ctx->task_len;
+    if (small_env > 0 && n <= ((size_t)1 << 16)) return (uint32_t)small_env;
+    return n >= ((size_t)1 << 18) ? KMAX : 16u;
+}
 
 // what a batch of `count` MSMs of n points needs beyond the slot's current capacity (0 = fits)
 static bool batch_need(const halo_ctx *ctx, const MsmWorkspace &ws, size_t n, int count, WorkspaceNeed &need) {
@@ -1032,7 +1072,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1);
+    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     // A graph is kept only while the same key keeps arriving on this slot (the bench loop, the rounds of an open)
     // and while no device memory of this library has been allocated or freed since it was instantiated: replaying
@@ -1103,6 +1143,17 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     }
     HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, dim3(gridn.x, (unsigned)p.batch), b256, 0, srcs, mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
                 d_digits, ws.d_meta, ws.d_blockoff);
+    // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
+    uint32_t kmax = msm_kmax(ctx, n);
+    if (ctx->small_path != 0 && n <= ((size_t)1 << 16) && p.batch == 1 && p.B <= 16384 &&
+        (size_t)Wt * p.B + n * (size_t)Wt / kmax + 1 <= (ws.cap_counts < ws.cap_tasks ? ws.cap_counts : ws.cap_tasks)) {  // smsm.hip: 4-5 launches in all
+        int rc = smsm_enqueue(ctx, ws, d_bases, members.base_off[0], n, p, Wt, kmax);
+        if (rc) return rc;
+        HALO_HIP(hipGetLastError());
+        HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
+        ws.plan = p;
+        return HALO_OK;
+    }
     // one block per (window, chunk): about one block per CU, chunks of at least 1024 scalars
     uint32_t nchunks = 256u / Wt;
     if (nchunks < 1) nchunks = 1;
@@ -1114,8 +1165,6 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     dim3 gridh((unsigned)(Wt * nchunks)), b1024(1024);
     size_t lds_bytes = (size_t)p.B * 4;
     uint32_t nblocks = (uint32_t)((total + 4095) / 4096);
-    // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
-    uint32_t kmax = msm_kmax(ctx, n);
     // large MSMs: two-level sort (coarse runs, then a fine sort per run) -- every store lands next to recent ones
     uint32_t NC = p.B >> FINE_BITS;
     bool two_level = vec && p.B >= (1u << FINE_BITS) && (size_t)Wt * NC <= 4096 && ws.d_presort &&

@@ -214,6 +214,9 @@ int halo_set_reduce_span(halo_ctx *ctx, int span);
 /* MSM tuning: bucket sort in one pass (0), in two (coarse runs, then a fine sort per run: 1, where the shape allows),
  * or chosen by size (-1, default: two levels from n = 2^17) */
 int halo_set_sort_mode(halo_ctx *ctx, int mode);
+/* MSM tuning: the 4-launch pipeline for MSMs of up to 2^16 points (sort per window in LDS, quad-parallel window sums):
+ * -1 automatic (default), 0 never (the general pipeline at every size).  Results are identical. */
+int halo_set_small_path(halo_ctx *ctx, int mode);
 /* MSM tuning: longest chain of mixed additions one lane runs in the bucket kernel (0 = automatic; 8, 16, 32, 64) */
 int halo_set_task_len(halo_ctx *ctx, int len);
 

@@ -203,15 +203,63 @@ def test_msm_tuning_knobs_do_not_change_results(hal, ctx16k, urs4096, span, task
     ctx16k.set_reduce_span(span)
     ctx16k.set_task_len(task_len)
     try:
-        for c in (0, 13):
-            ctx16k.set_window_bits(c)
-            assert ctx16k.msm(sc).tolist() == want
+        for small in (-1, 0):  # the 4-launch pipeline of smsm.hip, then the general one
+            ctx16k.set_small_path(small)
+            for c in (0, 13):
+                ctx16k.set_window_bits(c)
+                assert ctx16k.msm(sc).tolist() == want
     finally:
-        ctx16k.set_reduce_span(0); ctx16k.set_task_len(0); ctx16k.set_window_bits(0)
+        ctx16k.set_reduce_span(0); ctx16k.set_task_len(0); ctx16k.set_window_bits(0); ctx16k.set_small_path(-1)
     with pytest.raises(hal.HaloError):
         ctx16k.set_task_len(12)
     with pytest.raises(hal.HaloError):
         ctx16k.set_reduce_span(3)
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 1000, 4096, 16384])
+def test_msm_small_path_equals_general_path(hal, ctx16k, n):
+    """smsm.hip (sort per window in LDS, balanced tasks, quad-parallel window sums, last-block combine) against the general
+    pipeline and the oracle: random scalars; a fat bucket in every window (the whole-block pre-sum of heavy buckets);
+    two buckets holding equal values (P + P inside the quad additions); zeros; every window size the plan may pick."""
+    gs = ctx16k.read_bases(0, n)
+    sets = []
+    sc, s = orc.rng_scalars(31337 + n, n)
+    sets.append(sc)
+    fat = sc.copy(); fat[: max(1, n * 3 // 4)] = sc[0]; sets.append(fat)
+    z = sc.copy(); z[::3] = 0; z[1::3] = orc.fr_to_mont(1); sets.append(z)
+    eq = np.ascontiguousarray(np.tile(orc.fr_to_mont(3), (n, 1))); eq[n // 2:] = orc.fr_to_mont(5); sets.append(eq)
+    for k, scal in enumerate(sets):
+        want = orc.msm_affine(gs, scal).tolist()
+        for c in ((0, 4, 6, 8, 10, 13, 14) if n in (1000, 4096) else (0,)):
+            ctx16k.set_window_bits(c)
+            try:
+                ctx16k.set_small_path(-1)
+                a = ctx16k.msm(scal).tolist()
+                a2 = ctx16k.msm(scal).tolist()  # replayed as a graph on the third call
+                a3 = ctx16k.msm(scal).tolist()
+                ctx16k.set_small_path(0)
+                b = ctx16k.msm(scal).tolist()
+            finally:
+                ctx16k.set_small_path(-1); ctx16k.set_window_bits(0)
+            assert a == want and a2 == want and a3 == want and b == want, (n, k, c)
+
+
+def test_msm_small_path_same_base(hal, urs4096):
+    """every base equal: bucket values are multiples of one point, so equal buckets (P + P) and opposite ones occur in
+    the running sums of the quad-parallel reduce"""
+    n = 2048
+    same = np.ascontiguousarray(np.tile(urs4096[11], (n, 1)))
+    c = hal.Context(same)
+    try:
+        sc, _ = orc.rng_scalars(99, n)
+        sc[: n // 2] = orc.fr_to_mont(7)
+        neg = np.array([orc.fr_to_mont((pm.R_ORDER - orc.fr_from_mont(x)) % pm.R_ORDER) for x in sc[: n // 4]])
+        sc[n // 2: n // 2 + n // 4] = neg
+        for cbits in (0, 5, 9):
+            c.set_window_bits(cbits)
+            assert c.msm(sc).tolist() == orc.msm_affine(same, sc).tolist()
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("n,c", [(4096, 11), (4096, 13), (16384, 16), (1000, 13), (16384, 12)])
@@ -222,6 +270,7 @@ def test_msm_two_level_sort_equals_one_level(hal, ctx16k, urs4096, n, c):
     sc[100:600] = sc[3]
     sc[600:700] = 0
     ctx16k.set_window_bits(c)
+    ctx16k.set_small_path(0)  # the sort modes belong to the general pipeline
     try:
         ctx16k.set_sort_mode(0)
         one = ctx16k.msm(sc).tolist()
@@ -229,7 +278,7 @@ def test_msm_two_level_sort_equals_one_level(hal, ctx16k, urs4096, n, c):
         two = ctx16k.msm(sc).tolist()
         two_again = ctx16k.msm(sc).tolist()
     finally:
-        ctx16k.set_sort_mode(-1); ctx16k.set_window_bits(0)
+        ctx16k.set_sort_mode(-1); ctx16k.set_window_bits(0); ctx16k.set_small_path(-1)
     assert one == two == two_again
     if n <= 4096:
         assert one == orc.msm_affine(urs4096[:n], sc).tolist()

@@ -11,6 +11,7 @@ n = 1 << lg
 t = time.time(); ctx = h._lib.Context(urs_n=n); print("ctx urs %d: %.2fs" % (n, time.time() - t), flush=True)
 d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(2, n, d.data_ptr())  # the library's own SplitMix64 generator
+if len(sys.argv) > 3: ctx.set_small_path(int(sys.argv[3]))  # 0: general pipeline at every size
 for c in ([0] if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(",")]):
     ctx.set_window_bits(c)
     ctx.msm_dev(d.data_ptr(), n)
