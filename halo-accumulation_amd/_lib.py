@@ -102,6 +102,7 @@ _SIGS = {
     "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -172,9 +173,15 @@ class Context:
         self.h = h
         self.lib = lib
         self.device = device
+        self._children = []  # weak references to the Ipa states of this context: they must go before it
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             self.lib.halo_ctx_destroy(self.h)
             self.h = None
 
@@ -321,6 +328,9 @@ class Context:
     def set_sort_mode(self, mode):
         check(self.lib.halo_set_sort_mode(self.h, mode))
 
+    def set_fold_levels(self, levels):
+        check(self.lib.halo_set_fold_levels(self.h, levels))
+
     def set_small_path(self, mode):
         check(self.lib.halo_set_small_path(self.h, mode))
 
@@ -361,6 +371,8 @@ class Ipa:
         else:
             check(ctx.lib.halo_ipa_begin(ctx.h, n, ptr(coeffs), coeffs.shape[0], ptr(np.ascontiguousarray(z, dtype=np.uint64)), C.byref(h)))
         self.h, self.ctx = h, ctx
+        import weakref
+        ctx._children.append(weakref.ref(self))
 
     def dot_cz(self):
         out = np.zeros(4, dtype=np.uint64)

@@ -110,8 +110,7 @@ static int ipa_enter_nofold(halo_ipa *st) {
     st->s_len = 1;
     uint64_t *one = ctx->h_pinned + 200;
     host::Fr::one().store(one);
-    HALO_HIP(hipMemcpyAsync(st->d_s, one, 32, hipMemcpyHostToDevice, ctx->stream));
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    HALO_HIP(hipMemcpyAsync(st->d_s, one, 32, hipMemcpyHostToDevice, ctx->stream));  // the pinned word always holds 1: no wait needed
     return HALO_OK;
 }
 
@@ -155,11 +154,13 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
     do {
         // The context's own buffers (sized for the whole key on first use) serve one state at a time: the opens of a
         // prover loop allocate nothing.  A second concurrent state of the same context gets private buffers.
-        size_t M = n < kNoFoldSize ? n : kNoFoldSize;
+        // the no-fold vectors span the key the MSMs run over: the whole key when folds are deferred (two levels at a time)
+        bool defer = ctx->fold_levels >= 2 && n > kNoFoldSize;
+        size_t M = defer ? n : (n < kNoFoldSize ? n : kNoFoldSize);
         IpaBuffers &cb = ctx->ipa_bufs;
         IpaBuffers priv;
         if (!cb.in_use) {
-            size_t want_n = ctx->n > n ? ctx->n : n, want_M = want_n < kNoFoldSize ? want_n : kNoFoldSize;
+            size_t want_n = ctx->n > n ? ctx->n : n, want_M = (ctx->fold_levels >= 2 || want_n < kNoFoldSize) ? want_n : kNoFoldSize;
             if (want_M < M) want_M = M;
             if (cb.cap_n < n || cb.cap_M < M) {
                 for (int k = 0; k < HALO_SLOTS; ++k) (void)hipStreamSynchronize(ctx->streams[k]);
@@ -190,7 +191,9 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
             if (!rc && z_scale) rc = fr_scale(ctx, st->d_z, n, *z_scale);
         }
         if (rc) break;
-        if (n <= kNoFoldSize) rc = ipa_enter_nofold(st);
+        if (n <= kNoFoldSize || defer) rc = ipa_enter_nofold(st);
+        st->deferred = defer;
+        st->s_host.assign(1, host::Fr::one());
     } while (0);
     if (rc) { halo_ipa_destroy(st); return rc; }
     ctx->worker.set_hot(true);
@@ -642,12 +645,29 @@ int halo_ipa_round_fold(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_in
     if (st->nofold) {
         rc = nofold_s_update(ctx, st->d_s, st->s_len, x, st->d_s2);
         if (!rc) { std::swap(st->d_s, st->d_s2); st->s_len *= 2; }
+        if (!rc && st->deferred) {  // host copy of the (short) challenge products: s'[2t + u] = s[t] xi^u
+            std::vector<host::Fr> s2(2 * st->s_host.size());
+            for (size_t t = 0; t < st->s_host.size(); ++t) { s2[2 * t] = st->s_host[t]; s2[2 * t + 1] = st->s_host[t] * x; }
+            st->s_host.swap(s2);
+        }
     } else {
         rc = ipa_fold_points(ctx, st->d_G, m, x);
     }
     if (!rc) rc = ipa_fold_scalars(ctx, st->d_c, st->d_z, m, x, xinv);
     if (rc) return rc;
     st->m = m;
+    if (st->nofold && st->deferred && st->s_len == 4) {
+        // two rounds are due: G[j] <- G[j] + s1 G[j+m] + s2 G[j+2m] + s3 G[j+3m] with one shared doubling chain
+        rc = ipa_fold_points4(ctx, st->d_G, m, &st->s_host[1]);
+        if (rc) return rc;
+        st->deferred = m > kNoFoldSize;  // below the switch size the key stays as it is for the remaining rounds
+        st->s_host.assign(1, host::Fr::one());
+        if (m > 1) return ipa_enter_nofold(st);
+        st->nofold = false;  // the last two rounds: G[0] is U
+        st->M = 1;
+        st->s_len = 1;
+        return HALO_OK;
+    }
     if (!st->nofold && m <= kNoFoldSize && m > 1) rc = ipa_enter_nofold(st);
     return rc;
 }
@@ -892,6 +912,11 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode) {
 int halo_set_small_path(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
     ctx->small_path = mode;
+    return HALO_OK;
+}
+int halo_set_fold_levels(halo_ctx *ctx, int levels) {
+    if (!ctx || (levels != 1 && levels != 2)) { set_error("fold levels must be 1 or 2"); return HALO_E_ARG; }
+    ctx->fold_levels = levels;
     return HALO_OK;
 }
 int halo_set_task_len(halo_ctx *ctx, int len) {

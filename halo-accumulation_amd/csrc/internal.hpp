@@ -47,7 +47,7 @@ struct Profiler {
 };
 
 inline bool debug_trace() { static const bool on = getenv("HALO_TRACE") != nullptr; return on; }
-inline bool prof_is_dominant(const char *name) { return name[2] == 'm' ? name[6] == 'a' : (name[2] == 'f' && name[7] == 'p'); }
+inline bool prof_is_dominant(const char *name) { return name[2] == 'm' ? name[6] == 'a' : (name[2] == 'f' && name[7] == 'p'); }  // k_msm_accumulate, k_fold_points*
 // Launch wrapper: brackets the launch with events when profiling is on.
 #define HALO_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
     do {                                                                                     \
@@ -202,6 +202,7 @@ struct halo_ctx {
     int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
+    int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
@@ -225,6 +226,8 @@ struct halo_ipa {
     hipEvent_t ev = nullptr;  // orders slot 1's stream after the folds queued on stream 0
     // no-fold mode (ipa.hip): G stays at M points, s holds the challenge products
     bool nofold = false;
+    bool deferred = false;                   // the no-fold phase ends in a two-level fold once s_len reaches 4
+    std::vector<halo::host::Fr> s_host;      // host copy of s while deferred (<= 4 entries)
     size_t M = 0, s_len = 0;
     uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
     uint64_t *d_pbar = nullptr;  // n x 4: this shard of p_bar (hiding branch of the sharded open)
@@ -266,6 +269,7 @@ int smsm_prepare();
 
 // ---- ipa.hip
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont);
+int ipa_fold_points4(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr s[3]);
 int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv);
 // out[0] = <xs0, ys0>, out[1] = <xs1, ys1> (either pair may be null to skip)
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,

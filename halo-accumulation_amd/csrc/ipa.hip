@@ -102,6 +102,79 @@ __global__ __launch_bounds__(256) void k_fold_points(uint32_t *__restrict__ G, u
     if (two) aff_store(G + AFF_STRIDE * (size_t)(j + half), ob);
 }
 
+// ------------------------------------------------------------------ K3': two halving rounds of G in one pass
+// After two rounds without touching G the folded key is G''[j] = G[j] + s1 G[j+m] + s2 G[j+2m] + s3 G[j+3m] with
+// (s1, s2, s3) = (xi_2, xi_1, xi_1 xi_2), m = a quarter of the key (pcdl.rs:218 applied twice).  The three scalar
+// multiplications share ONE doubling chain (Straus): ~128 doublings + 3 x ~71 additions per output instead of
+// 2 x (128 + 71) for each of the 1.5 outputs the two separate folds produce -- ~38 % fewer field products for the
+// same two rounds.  The rounds in between take L and R from MSMs over the unfolded key (the "no-fold" form below).
+struct GlvArg3 {
+    uint32_t dig[3][14];  // as GlvArg, one digit string per scalar
+    int ndigits;          // longest of the three
+};
+HALO_DEV JacN fold_one4(const uint32_t *__restrict__ G, uint32_t j, uint32_t m, const GlvArg3 &a) {
+    constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
+    constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
+    AffN p1 = aff_load(G + AFF_STRIDE * (size_t)(j + m)), p2 = aff_load(G + AFF_STRIDE * (size_t)(j + 2 * m)),
+         p3 = aff_load(G + AFF_STRIDE * (size_t)(j + 3 * m));
+    bool live1 = !aff_is_inf(p1), live2 = !aff_is_inf(p2), live3 = !aff_is_inf(p3);
+    // acc += unit(code) * p: code is wave-uniform; lambda^e * (x, y) = (beta^e x, y)
+    auto step = [&](JacN &acc, const AffN &p, bool live, uint32_t code) {
+        if (!code) return;
+        int e = (int)((code - 1) % 3);
+        AffN q;
+        q.x = p.x;
+        if (e) q.x = fq_mul(p.x, fq_const(e == 1 ? BETA : BETA2));
+        q.y = code > 3 ? fq_neg<2>(p.y) : p.y;
+        if (live) acc = jac_madd(acc, q);
+    };
+    JacN acc = jac_inf();
+    int top = a.ndigits - 1;
+#pragma unroll 1
+    for (int word = top / 10; word >= 0; word--) {
+        uint32_t w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+        for (int q = 0; q < 14; q++) {
+            w1 = (q == word) ? a.dig[0][q] : w1;
+            w2 = (q == word) ? a.dig[1][q] : w2;
+            w3 = (q == word) ? a.dig[2][q] : w3;
+        }
+#pragma unroll 1
+        for (int k = (word == top / 10) ? (top % 10) : 9; k >= 0; k--) {
+            acc = jac_dbl(acc);
+            step(acc, p1, live1, (w1 >> (3 * k)) & 7u);
+            step(acc, p2, live2, (w2 >> (3 * k)) & 7u);
+            step(acc, p3, live3, (w3 >> (3 * k)) & 7u);
+        }
+    }
+    return jac_madd(acc, aff_load(G + AFF_STRIDE * (size_t)j));
+}
+__global__ __launch_bounds__(256) void k_fold_points4(uint32_t *__restrict__ G, uint32_t m, uint32_t half, GlvArg3 a) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= half) return;
+    bool two = j + half < m;
+    JacN ra = fold_one4(G, j, m, a);
+    JacN rb = jac_inf();
+    if (two) rb = fold_one4(G, j + half, m, a);
+    bool ia = jac_is_inf(ra), ib = jac_is_inf(rb);
+    Fq<4> za = ia ? fq_widen<4>(fq_one()) : ra.z, zb = ib ? fq_widen<4>(fq_one()) : rb.z;
+    Fq<2> zi = fq_inv(fq_mul(za, zb));
+    Fq<2> zia = fq_mul(zi, zb), zib = fq_mul(zi, za);
+    AffN oa = aff_inf(), ob = aff_inf();
+    if (!ia) {
+        Fq<2> z2 = fq_sqr(zia);
+        oa.x = fq_mul(ra.x, z2);
+        oa.y = fq_mul(ra.y, fq_mul(z2, zia));
+    }
+    if (!ib) {
+        Fq<2> z2 = fq_sqr(zib);
+        ob.x = fq_mul(rb.x, z2);
+        ob.y = fq_mul(rb.y, fq_mul(z2, zib));
+    }
+    aff_store(G + AFF_STRIDE * (size_t)j, oa);
+    if (two) aff_store(G + AFF_STRIDE * (size_t)(j + half), ob);
+}
+
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
 __global__ __launch_bounds__(256) void k_fold_scalars(uint64_t *__restrict__ c, uint64_t *__restrict__ z, uint32_t m, FeArg xi,
                                                       FeArg xi_inv) {
@@ -361,6 +434,22 @@ int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_m
     // a lane folds the points j and j + half where that still leaves >= 4 waves per SIMD; below, one point per lane
     size_t half = m >= ((size_t)1 << 18) ? (m + 1) / 2 : m;
     HALO_LAUNCH(ctx, "k_fold_points", k_fold_points, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, (uint32_t)half, a);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+// G[j] <- G[j] + s[0] G[j+m] + s[1] G[j+2m] + s[2] G[j+3m], j < m
+int ipa_fold_points4(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr s[3]) {
+    if (m == 0) return HALO_OK;
+    GlvArg3 a;
+    a.ndigits = 0;
+    for (int t = 0; t < 3; ++t) {
+        host::GlvDigits dg = host::glv_digits(s[t]);
+        for (int i = 0; i < 14; ++i) a.dig[t][i] = 0;
+        for (int i = 0; i < dg.n; ++i) a.dig[t][i / 10] |= (uint32_t)dg.d[i] << (3 * (i % 10));
+        if (dg.n > a.ndigits) a.ndigits = dg.n;
+    }
+    size_t half = m >= ((size_t)1 << 17) ? (m + 1) / 2 : m;
+    HALO_LAUNCH(ctx, "k_fold_points4", k_fold_points4, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, (uint32_t)half, a);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

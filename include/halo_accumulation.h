@@ -207,6 +207,9 @@ int halo_set_graphs(halo_ctx *ctx, int on);  /* also: environment HALO_GRAPHS=0 
 /* IPA tuning: key size at which halo_ipa_* stops folding G and switches to MSMs over the fixed
  * folded key (default 2^16; 0 or 1 = always fold).  Results are identical either way. */
 int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
+/* IPA tuning: 2 (default) folds G every other round, two halvings at once with one shared doubling chain, the rounds in
+ * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */
+int halo_set_fold_levels(halo_ctx *ctx, int levels);
 /* MSM tuning: window bits (0 = automatic) */
 int halo_set_window_bits(halo_ctx *ctx, int c);
 /* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */

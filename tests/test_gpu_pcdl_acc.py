@@ -98,13 +98,17 @@ def test_u_check(hal, ctx, ipa_mode):
     assert [orc.fr_from_mont(c) for c in ctx.h_coeffs(xm)] == [1, 3, 2, 6, 1, 3, 2, 6]
 
 
-@pytest.fixture(params=[0, 1 << 16, 16], ids=["always-fold", "default-switch", "switch-at-16"])
+@pytest.fixture(params=[(0, 1), (1 << 16, 2), (16, 1), (0, 2), (16, 2)],
+                ids=["always-fold", "default", "switch-at-16", "two-level-folds-to-the-end", "two-level-folds-switch-at-16"])
 def ipa_mode(request, ctx):
-    """Both IPA strategies must give the reference's results: folding G every round (k_fold_points)
-    and the no-fold late rounds (MSMs over the fixed folded key)."""
-    ctx.set_ipa_switch(request.param)
+    """Every IPA strategy must give the reference's results: folding G every round (k_fold_points), every other round
+    (two halvings per pass, k_fold_points4, L/R from MSMs over the unfolded key in between) and the no-fold late rounds
+    (MSMs over the fixed folded key)."""
+    ctx.set_ipa_switch(request.param[0])
+    ctx.set_fold_levels(request.param[1])
     yield request.param
     ctx.set_ipa_switch(1 << 16)
+    ctx.set_fold_levels(2)
 
 
 @pytest.mark.parametrize("n", [2, 8, 64, 1024])
@@ -242,10 +246,11 @@ def test_open_2_17_both_strategies_agree(hal):
         zw, _ = orc.rng_scalars(s, 2)
         C = pcdl.commit(c, coeffs, d, zw[1])
         proofs = []
-        for switch in (1 << 16, 0, 1 << 10):
+        for switch, levels in ((1 << 16, 2), (0, 1), (1 << 10, 1), (1 << 10, 2), (1 << 16, 1)):
             c.set_ipa_switch(switch)
+            c.set_fold_levels(levels)
             proofs.append(pcdl.open(c, [5], coeffs, C, d, zw[0], zw[1]))
-        assert proofs[0].tolist() == proofs[1].tolist() == proofs[2].tolist()
+        assert all(p.tolist() == proofs[0].tolist() for p in proofs)
         pcdl.check_proof(c, C, d, zw[0], c.poly_eval(coeffs, zw[0]), proofs[0])
     finally:
         c.close()
