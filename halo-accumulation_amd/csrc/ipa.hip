@@ -149,13 +149,27 @@ HALO_DEV JacN fold_one4(const uint32_t *__restrict__ G, uint32_t j, uint32_t m, 
     }
     return jac_madd(acc, aff_load(G + AFF_STRIDE * (size_t)j));
 }
-__global__ __launch_bounds__(256) void k_fold_points4(uint32_t *__restrict__ G, uint32_t m, uint32_t half, GlvArg3 a) {
+__global__ __launch_bounds__(256, 2) void k_fold_points4(uint32_t *__restrict__ G, uint32_t m, uint32_t half, GlvArg3 a) {
+    // the first result waits in LDS while the second ladder runs (three bases + the accumulator + a mixed addition's
+    // temporaries fill the 256 registers that two waves per SIMD allow); word k of thread t at park[256 k + t]
+    __shared__ uint32_t park[27 * 256];
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= half) return;
     bool two = j + half < m;
-    JacN ra = fold_one4(G, j, m, a);
     JacN rb = jac_inf();
+    {
+        JacN ra0 = fold_one4(G, j, m, a);
+        uint32_t *mine = park + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { mine[256 * k] = ra0.x.v[k]; mine[256 * (9 + k)] = ra0.y.v[k]; mine[256 * (18 + k)] = ra0.z.v[k]; }
+    }
     if (two) rb = fold_one4(G, j + half, m, a);
+    JacN ra;
+    {
+        const uint32_t *mine = park + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { ra.x.v[k] = mine[256 * k]; ra.y.v[k] = mine[256 * (9 + k)]; ra.z.v[k] = mine[256 * (18 + k)]; }
+    }
     bool ia = jac_is_inf(ra), ib = jac_is_inf(rb);
     Fq<4> za = ia ? fq_widen<4>(fq_one()) : ra.z, zb = ib ? fq_widen<4>(fq_one()) : rb.z;
     Fq<2> zi = fq_inv(fq_mul(za, zb));
