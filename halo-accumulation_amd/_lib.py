@@ -90,6 +90,15 @@ _SIGS = {
     "halo_acc_verifier": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_decider": (C.c_int, [C.c_void_p, u64p]),
     "halo_random_instance": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p]),
+    "halo_proof_encoded_size": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "halo_instance_encoded_size": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "halo_accumulator_encoded_size": (C.c_size_t, [C.c_size_t]),
+    "halo_proof_encode": (C.c_int, [u64p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "halo_proof_decode": (C.c_int, [C.c_char_p, C.c_size_t, u64p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "halo_instance_encode": (C.c_int, [u64p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "halo_instance_decode": (C.c_int, [C.c_char_p, C.c_size_t, u64p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "halo_accumulator_encode": (C.c_int, [u64p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "halo_accumulator_decode": (C.c_int, [C.c_char_p, C.c_size_t, u64p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "halo_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_prof_reset": (C.c_int, [C.c_void_p]),
     "halo_prof_count": (C.c_int, [C.c_void_p]),
@@ -456,6 +465,53 @@ def open_combine(parts, Hp, xi_prev):
     check(load().halo_open_combine(ptr(parts), parts.shape[0], ptr(np.ascontiguousarray(Hp, dtype=np.uint64)),
                                    ptr(np.ascontiguousarray(xi_prev, dtype=np.uint64)), ptr(L), ptr(R), ptr(xi), ptr(xi_inv)))
     return L, R, xi, xi_inv
+
+
+def _encode(fn, blob, cap):
+    blob = np.ascontiguousarray(blob, dtype=np.uint64)
+    buf = C.create_string_buffer(cap)
+    n = C.c_size_t()
+    check(fn(ptr(blob), buf, cap, C.byref(n)))
+    return buf.raw[: n.value]
+
+
+def _decode(fn, data, words_of_lg):
+    data = bytes(data)
+    out = np.zeros(words_of_lg(40), dtype=np.uint64)
+    lg = C.c_size_t()
+    check(fn(data, len(data), ptr(out), out.shape[0], C.byref(lg)))
+    return out[: words_of_lg(lg.value)].copy()
+
+
+def proof_encode(proof):
+    """EvalProof blob -> bytes (ark-serialize compressed layout of pcdl.rs:22-30)"""
+    lib = load()
+    return _encode(lib.halo_proof_encode, proof, lib.halo_proof_encoded_size(int(proof[1]), 1))
+
+
+def proof_decode(data):
+    lib = load()
+    return _decode(lib.halo_proof_decode, data, lib.halo_proof_words)
+
+
+def instance_encode(inst):
+    lib = load()
+    return _encode(lib.halo_instance_encode, inst, lib.halo_instance_encoded_size(int(inst[22]), 1))
+
+
+def instance_decode(data):
+    lib = load()
+    return _decode(lib.halo_instance_decode, data, lib.halo_instance_words)
+
+
+def accumulator_encode(acc):
+    lib = load()
+    return _encode(lib.halo_accumulator_encode, acc, lib.halo_accumulator_encoded_size(int(acc[22])))
+
+
+def accumulator_decode(data):
+    lib = load()
+    return _decode(lib.halo_accumulator_decode, data, lib.halo_accumulator_words)
 
 
 def point_sum(pts_jac):

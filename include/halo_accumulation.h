@@ -188,6 +188,22 @@ int halo_acc_decider(halo_ctx *ctx, const uint64_t *acc);
 /* benches/acc.rs:15-29 random_instance: the workload generator of the reference's benchmark */
 int halo_random_instance(halo_ctx *ctx, uint64_t *rng_state, size_t d, uint64_t *instance_out);
 
+/* ---- wire format (host only; no device needed) ----------------------------------------------
+ * EvalProof (pcdl.rs:22-30), Instance (acc.rs:21-28) and Accumulator (acc.rs:43-59) in the byte layout a derived
+ * ark-serialize `CanonicalSerialize` (compressed) writes: fields in declaration order; Fr = 32 bytes LE canonical;
+ * point = 33 bytes (x LE, byte 32: bit 7 = y is the larger of {y, -y}, bit 6 = infinity); usize = u64 LE; Vec = u64 LE
+ * length + elements; Option = 1 byte tag + value.  decode() validates canonical scalars, flag bits and curve membership
+ * and returns HALO_E_REJECT on malformed input; blobs are the flat u64 layouts above. */
+size_t halo_proof_encoded_size(size_t lg_n, int hiding);
+size_t halo_instance_encoded_size(size_t lg_n, int hiding);
+size_t halo_accumulator_encoded_size(size_t lg_n); /* upper bound */
+int halo_proof_encode(const uint64_t *proof, uint8_t *out, size_t cap, size_t *len);
+int halo_proof_decode(const uint8_t *in, size_t len, uint64_t *proof_out, size_t cap_words, size_t *lg_n);
+int halo_instance_encode(const uint64_t *instance, uint8_t *out, size_t cap, size_t *len);
+int halo_instance_decode(const uint8_t *in, size_t len, uint64_t *instance_out, size_t cap_words, size_t *lg_n);
+int halo_accumulator_encode(const uint64_t *acc, uint8_t *out, size_t cap, size_t *len);
+int halo_accumulator_decode(const uint8_t *in, size_t len, uint64_t *acc_out, size_t cap_words, size_t *lg_n);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */
 /* on = 1: every kernel launch on this ctx is bracketed by hipEvents on the ctx stream;
  * on = 2: only the dominant kernels (k_msm_accumulate, k_fold_points); 0: off. */
@@ -229,7 +245,8 @@ int halo_set_task_len(halo_ctx *ctx, int len);
 int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n);
 int halo_test_field_op(halo_ctx *ctx, int field /*0 Fq, 1 Fr*/, int op /*0 mul,1 add,2 sub,3 inv,4 from_mont,5 to_mont*/,
                        const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
-/* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs) */
+/* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs);
+ * 4, 5, 6: the quad-parallel forms (curve_quad.cuh): a + b, 2a, a + b with every fourth b replaced by a */
 int halo_test_point_op(halo_ctx *ctx, int op, const uint64_t *a_jac, const uint64_t *b, size_t n, uint64_t *out_jac);
 
 #ifdef __cplusplus

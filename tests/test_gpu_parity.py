@@ -160,6 +160,30 @@ def test_point_ops(ctx16k, urs4096):
         assert canon(got[i]) == canon(want), i
 
 
+def test_quad_parallel_point_ops(ctx16k, urs4096):
+    """curve_quad.cuh: one XYZZ addition / doubling shared by the 4 lanes of a quad (DPP broadcasts), against the oracle.
+    op 4 = a + b, op 5 = 2a, op 6 = a + b with every fourth pair replaced by (a, a), so that general additions and the
+    wave-wide doubling branch mix inside one wave; un-normalised inputs, infinity on either side, P + (-P)."""
+    n = 300
+    lams, _ = orc.rng_scalars(4321, 2 * n)
+    lams[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    a = np.zeros((n, 12), dtype=np.uint64); b = np.zeros((n, 12), dtype=np.uint64)
+    for i in range(n):
+        orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(a[i])); orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i + n]), orc.ptr(b[i]))
+        if i % 3:
+            a[i] = unnormalise(a[i], lams[i]); b[i] = unnormalise(b[i], lams[n + i])
+    b[5] = unnormalise(a[5], lams[7])                      # P + P, two representatives
+    neg = orc.z(12); orc.lib().orc_point_mul(orc.ptr(a[6]), orc.ptr(orc.fr_to_mont(pm.R_ORDER - 1)), orc.ptr(neg)); b[6] = neg
+    inf = np.array(list(a[2][:8]) + [0, 0, 0, 0], dtype=np.uint64)
+    a[9] = inf; b[10] = inf; a[11] = inf; b[11] = inf
+    for op in (4, 5, 6):
+        got = ctx16k.point_op(op, a, b)
+        for i in range(n):
+            bb = a[i] if (op == 5 or (op == 6 and i % 4 == 3)) else b[i]
+            want = orc.z(12); orc.lib().orc_point_add(orc.ptr(a[i]), orc.ptr(bb), orc.ptr(want))
+            assert canon(got[i]) == canon(want), (op, i)
+
+
 # ------------------------------------------------------------------ K1/K2 MSM
 EDGE = [0, 1, pm.R_ORDER - 1, 1 << 254, 2, pm.R_ORDER - 2]
 
