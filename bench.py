@@ -165,9 +165,10 @@ def main():
 
     result = None
     if rank == 0:
-        acc_ms, acc_cnt = prof_solo.get("k_msm_accumulate", (0.0, 0))
+        dom = "k_msm_accumulate" if "k_msm_accumulate" in prof_solo else "k_smsm_accumulate"  # n <= 2^16: the small-MSM pipeline
+        acc_ms, acc_cnt = prof_solo.get(dom, (0.0, 0))
         kern_s = acc_ms / max(acc_cnt, 1) * 1e-3
-        ovl_ms, ovl_cnt = prof.get("k_msm_accumulate", (0.0, 0))
+        ovl_ms, ovl_cnt = prof.get(dom, (0.0, 0))
         # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
         # index block or their 1/parts window share on this rank)
         alg_bytes = batch * (96 * (hi - lo) // parts + 64)
@@ -197,7 +198,7 @@ def main():
                                     else "block index shard per rank + RCCL all-gather of 96 B partials"),
                        "msms_per_launch": batch, "launches_in_flight": args.depth,
                        "window_bits": "auto (16 at n >= 2^20; measured table below, msm.hip msm_plan)"},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
                          "algorithmic_bytes": alg_bytes, "valu": valu,

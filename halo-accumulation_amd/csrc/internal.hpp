@@ -47,7 +47,10 @@ struct Profiler {
 };
 
 inline bool debug_trace() { static const bool on = getenv("HALO_TRACE") != nullptr; return on; }
-inline bool prof_is_dominant(const char *name) { return name[2] == 'm' ? name[6] == 'a' : (name[2] == 'f' && name[7] == 'p'); }  // k_msm_accumulate, k_fold_points*
+// k_msm_accumulate, k_smsm_accumulate, k_fold_points, k_fold_points4
+inline bool prof_is_dominant(const char *name) {
+    return name[2] == 'm' ? name[6] == 'a' : name[2] == 's' ? name[7] == 'a' : (name[2] == 'f' && name[7] == 'p');
+}
 // Launch wrapper: brackets the launch with events when profiling is on.
 #define HALO_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
     do {                                                                                     \
