@@ -111,6 +111,7 @@ _SIGS = {
     "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_table_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
@@ -339,6 +340,9 @@ class Context:
 
     def set_fold_levels(self, levels):
         check(self.lib.halo_set_fold_levels(self.h, levels))
+
+    def set_table_mode(self, mode):
+        check(self.lib.halo_set_table_mode(self.h, mode))
 
     def set_small_path(self, mode):
         check(self.lib.halo_set_small_path(self.h, mode))

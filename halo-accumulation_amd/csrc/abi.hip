@@ -909,6 +909,11 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode) {
     ctx->sort_two_level = mode;
     return HALO_OK;
 }
+int halo_set_table_mode(halo_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 0) { set_error("table mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
+    ctx->table_mode = mode;
+    return HALO_OK;
+}
 int halo_set_small_path(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
     ctx->small_path = mode;

@@ -67,6 +67,7 @@ struct MsmPlan {
     uint32_t B;   // buckets per window = 2^(c-1)
     int batch;    // MSMs sharing the launch sequence (their windows are laid side by side: W * batch in all)
     int w0, w1;   // windows [w0, w1) of 0..W are computed (a window-sharded partial); the result carries 2^(c*w0)
+    int table_vw = 0;  // > 0: the fixed-base table pipeline ran; h_winsum holds table_vw weighted sums, then table_vw plain sums
 };
 constexpr int MSM_MAX_BATCH = 8;
 // the members of a batched launch: same n, one scalar array and one base offset (in points) each
@@ -90,6 +91,7 @@ struct MsmWorkspace {
     uint32_t *d_buckets = nullptr;   // one native XYZZ partial (40 words) per task
     uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
     uint32_t *d_task_g = nullptr, *d_order = nullptr;  // per task: bucket | length bin << 24; tasks by decreasing length
+    uint16_t *d_fine16 = nullptr;    // table pipeline: low bucket bits beside d_presort (allocated on first use)
     uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
@@ -202,6 +204,8 @@ struct halo_ctx {
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
     int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^17), 0 never, 1 whenever the shape allows
     int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
+    int table_mode = -1;                   // fixed-base tables for MSMs over the context's own bases: -1 automatic (n >= 2^20), 0 never
+    uint32_t *d_table = nullptr;           // TBL_W x n native affine points: T[w][i] = 2^(20 w) G_i (built on first use)
     int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)

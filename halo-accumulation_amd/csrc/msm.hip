@@ -385,6 +385,232 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------ fixed-base tables (the commitment key is constant)
+// The key of a context never changes (consts.rs:68: GS is a compile-time constant of the reference), and a 288 GB device has
+// room to spare, so for large MSMs over the context's own bases the context keeps T[w][i] = 2^(c w) G_i for every window w
+// (c = 20: 13 windows, 13 x 128 B per point).  A signed digit d of window w then sends the point T[w][i] to bucket |d| of ONE
+// set of 2^19 buckets shared by all windows:
+//   * 13 n mixed additions instead of 16 n (the general pipeline cannot go past c = 16: every window would need its own
+//     2^(c-1) buckets reduced);
+//   * the weighted bucket sum is taken once over 2^19 buckets -- as many as 16 windows x 2^15 today -- and the host no longer
+//     runs a 240-doubling Horner chain: it combines 16 (plain, weighted) pairs with ~50 additions.
+// The sort is the two-level one (coarse: 512 bucket ranges, runs advance sequentially; fine: one block per range, 1024 buckets,
+// staged in LDS); everything after it (tasks, k_msm_accumulate, combine, window sums) is the general pipeline's, which sees
+// 16 "virtual windows" of 2^15 buckets.
+constexpr int TBL_C = 20, TBL_W = 13;
+constexpr uint32_t TBL_B = 1u << (TBL_C - 1);         // buckets
+constexpr uint32_t TBL_RANGES = TBL_B >> 10;          // coarse ranges of 1024 buckets
+constexpr uint32_t TBL_VW = TBL_B >> 15;              // virtual windows of 2^15 buckets for the window-sum kernels
+constexpr uint32_t TDIGIT_NONE = 0xFFFFFFFFu;
+
+// next[i] = 2^c * prev[i], affine in, affine out (one Fermat inversion per point: paid once per context)
+__global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__ prev, uint32_t n, int c, uint32_t *__restrict__ next) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    JacN p = jac_from_aff(aff_load(prev + AFF_STRIDE * (size_t)i));
+#pragma unroll 1
+    for (int k = 0; k < c; k++) p = jac_dbl(p);
+    aff_store(next + AFF_STRIDE * (size_t)i, jac_to_aff(p));
+}
+
+// signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
+__global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, uint32_t *__restrict__ digits,
+                                                     uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b) {
+    __shared__ uint32_t sw[256 * 9];
+    if (blockIdx.x == 0) {
+        meta[threadIdx.x] = 0;
+        for (int k = 0; k < 4; k++) zero_b[threadIdx.x + 256 * k] = 0;
+    }
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fe s = fe_load(scalars + 4 * (size_t)i);
+    if (mont) s = fe_from_mont<FrCfg>(s);
+    uint32_t *my = sw + threadIdx.x * 9;
+#pragma unroll
+    for (int k = 0; k < 8; k++) my[k] = s.v[k];
+    my[8] = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < TBL_W; w++) {
+        Digit d = next_digit(my, w, TBL_C, TBL_B, carry);
+        digits[(size_t)w * n + i] = d.mag ? ((d.mag - 1) | (d.neg << 31)) : TDIGIT_NONE;
+    }
+}
+// block (w, chunk): counts of the 512 coarse ranges, one private row per wave
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                           uint32_t *__restrict__ chist) {
+    __shared__ uint32_t cnt[16 * TBL_RANGES];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    for (uint32_t k = threadIdx.x; k < 16 * TBL_RANGES; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    uint32_t *mine = cnt + TBL_RANGES * (threadIdx.x >> 6);
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    for (uint32_t i = lo + 4 * threadIdx.x; i < hi; i += 4 * 1024) {  // n and chunk_len are multiples of 4
+        uint4 q = *reinterpret_cast<const uint4 *>(dg + i);
+        uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (v[k] != TDIGIT_NONE) atomicAdd(&mine[(v[k] & 0x7FFFFu) >> 10], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < TBL_RANGES) {
+        uint32_t t = 0;
+        for (int r = 0; r < 16; r++) t += cnt[TBL_RANGES * r + threadIdx.x];
+        chist[(size_t)blockIdx.x * TBL_RANGES + threadIdx.x] = t;
+    }
+}
+// chist[chunk][range] -> exclusive prefix over the chunks of each range (in place); rtotal[range] = the range's size.
+// One block per range: 247 counters, loaded once, scanned in LDS.
+__global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__ chist, uint32_t nchunks_all, uint32_t *__restrict__ rtotal) {
+    __shared__ uint32_t part[256];
+    uint32_t r = blockIdx.x, t = threadIdx.x;
+    uint32_t v = t < nchunks_all ? chist[(size_t)t * TBL_RANGES + r] : 0u;  // nchunks_all <= 256
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t o = t >= (uint32_t)off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    if (t < nchunks_all) chist[(size_t)t * TBL_RANGES + r] = part[t] - v;
+    if (t == 255) rtotal[r] = part[255];
+}
+// cstart[r] = start of run r in the presorted array, cstart[512] = number of entries
+__global__ __launch_bounds__(512) void k_tmsm_scan_ranges(const uint32_t *__restrict__ rtotal, uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t part[TBL_RANGES];
+    uint32_t t = threadIdx.x, v = rtotal[t];
+    part[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < TBL_RANGES; off <<= 1) {
+        uint32_t o = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += o;
+        __syncthreads();
+    }
+    cstart[t] = part[t] - v;
+    if (t == TBL_RANGES - 1) cstart[TBL_RANGES] = part[t];
+}
+// Block (w, chunk) appends its entries to the 512 runs: table index | sign << 31, and the bucket's low 10 bits beside it.
+// 247 blocks x 512 runs are too many open cache lines for direct appends (partially filled lines would be evicted and
+// rewritten), so the block goes through its chunk in tiles of 8192 entries: a tile is grouped by range in LDS (local
+// ranks from an LDS histogram), then written out in that order -- entries of one range land on consecutive addresses.
+constexpr uint32_t TBL_TILE = 8192;
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                              const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
+                                                              uint32_t table_n, uint32_t base_off, uint32_t *__restrict__ presort,
+                                                              uint16_t *__restrict__ presort_fine) {
+    __shared__ uint32_t cur[TBL_RANGES], tcount[TBL_RANGES], toff[TBL_RANGES];
+    __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
+    __shared__ uint16_t t_fine[TBL_TILE];
+    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, tid = threadIdx.x;
+    if (tid < TBL_RANGES) cur[tid] = cstart[tid] + chist[(size_t)blockIdx.x * TBL_RANGES + tid];
+    uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+    const uint32_t *dg = digits + (size_t)w * n;
+    uint32_t tbase = w * table_n + base_off;
+    for (uint32_t t0 = lo; t0 < hi; t0 += TBL_TILE) {
+        if (tid < TBL_RANGES) tcount[tid] = 0;
+        __syncthreads();
+        // eight digits per thread: two 16-byte loads (n, chunk_len and the tile are multiples of 4)
+        uint32_t v[8], rank[8];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t i = t0 + 4 * tid + (uint32_t)h * 4096;
+            uint4 q = i < hi ? *reinterpret_cast<const uint4 *>(dg + i) : make_uint4(TDIGIT_NONE, TDIGIT_NONE, TDIGIT_NONE, TDIGIT_NONE);
+            v[4 * h] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & 0x7FFFFu) >> 10], 1u) : 0u;
+        __syncthreads();
+        if (tid < TBL_RANGES) toff[tid] = tcount[tid];
+        __syncthreads();
+        for (uint32_t off = 1; off < TBL_RANGES; off <<= 1) {  // inclusive scan of the tile's counts (threads 0..511)
+            uint32_t o = (tid < TBL_RANGES && tid >= off) ? toff[tid - off] : 0u;
+            __syncthreads();
+            if (tid < TBL_RANGES) toff[tid] += o;
+            __syncthreads();
+        }
+        uint32_t total = toff[TBL_RANGES - 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (v[k] != TDIGIT_NONE) {
+                uint32_t r = (v[k] & 0x7FFFFu) >> 10;
+                uint32_t slot = toff[r] - tcount[r] + rank[k];
+                uint32_t i = t0 + 4 * tid + (uint32_t)(k >> 2) * 4096 + (uint32_t)(k & 3);
+                t_idx[slot] = (tbase + i) | (v[k] & 0x80000000u);
+                t_fine[slot] = (uint16_t)(v[k] & 0x3FFu);
+                t_dest[slot] = cur[r] + rank[k];
+            }
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += 1024) {
+            uint32_t d = t_dest[j];
+            presort[d] = t_idx[j];
+            presort_fine[d] = t_fine[j];
+        }
+        __syncthreads();
+        if (tid < TBL_RANGES) cur[tid] += tcount[tid];
+    }
+}
+// fine sort of run r: counts / absolute starts / task counts of its 1024 buckets, entries placed in [lo, hi) of `sorted`
+__global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ presort_fine,
+                                                         const uint32_t *__restrict__ cstart, uint32_t kmax, uint32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t hist[1024], scan[1024];
+    uint32_t r = blockIdx.x, lo = cstart[r], hi = cstart[r + 1];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
+        uint32_t f[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) f[k] = e + k * 1024 < hi ? presort_fine[e + k * 1024] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e + k * 1024 < hi) atomicAdd(&hist[f[k]], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = hist[threadIdx.x];
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t t = threadIdx.x >= o ? scan[threadIdx.x - o] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    {
+        uint32_t begin = lo + scan[threadIdx.x] - mine;
+        uint32_t g = (r << 10) + threadIdx.x;
+        counts[g] = mine;
+        ntask[g] = (mine + kmax - 1) / kmax;
+        starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
+        hist[threadIdx.x] = begin;
+    }
+    __syncthreads();
+    extern __shared__ uint32_t stage[];  // FINE_STAGE entries
+    bool staged = hi - lo <= FINE_STAGE;
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
+        uint32_t v[4], f[4], pos[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bool in = e + k * 1024 < hi;
+            v[k] = in ? presort[e + k * 1024] : 0u;
+            f[k] = in ? presort_fine[e + k * 1024] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) pos[k] = e + k * 1024 < hi ? atomicAdd(&hist[f[k]], 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e + k * 1024 < hi) {
+                if (staged) stage[pos[k] - lo] = v[k];
+                else sorted[pos[k]] = v[k];
+            }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += 1024) sorted[e] = stage[e - lo];
+    }
+}
+
 // ------------------------------------------------------------------------------ scan
 // 4096 entries per block: local exclusive scan + block total.
 __global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t total, uint32_t *__restrict__ out,
@@ -658,7 +884,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
 }
 // one wave per window over its nseg <= 64 segments; segment stride = 64*L buckets = 2^seg_shift
 __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__ seg, uint32_t nseg, int seg_shift,
-                                                    uint64_t *__restrict__ winsum) {
+                                                    uint64_t *__restrict__ winsum, uint64_t *__restrict__ winsum_plain) {
     __shared__ uint32_t park[36 * 64];
     uint32_t w = blockIdx.x, lane = threadIdx.x;
     XyzzN S = xyzz_inf(), T = xyzz_inf();
@@ -668,7 +894,10 @@ __global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__
         T = xyzz_load(o + XYZZ_WORDS);
     }
     wave_weighted_sum(S, T, seg_shift, park, (int)nseg);  // only nseg lanes hold a segment
-    if (lane == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
+    if (lane == 0) {
+        xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
+        if (winsum_plain) xyzz_store_jac_words(winsum_plain + 12 * (size_t)w, S);  // the unweighted sum (table pipeline)
+    }
 }
 
 // ------------------------------------------------------------------------------ K10 / K11 / format conversion
@@ -926,6 +1155,7 @@ static void workspace_release(MsmWorkspace &ws) {
                        ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
     for (auto p : p64) (void)hipFree(p);
     for (auto p : p32) (void)hipFree(p);
+    (void)hipFree(ws.d_fine16);
     if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
     if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
     ws = MsmWorkspace();
@@ -942,6 +1172,7 @@ static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tmsm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
     { int rc = smsm_prepare(); if (rc) return rc; }
     HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
     HALO_HIP(hipMalloc(&ws.d_hist, ws.cap_hist * 4));          // [w][chunk][b]
@@ -983,6 +1214,8 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
 }
 void msm_workspace_free(halo_ctx *ctx) {
     alloc_epoch_bump(ctx);
+    (void)hipFree(ctx->d_table);
+    ctx->d_table = nullptr;
     for (int slot = 0; slot < HALO_SLOTS; ++slot) workspace_release(ctx->wss[slot]);
 }
 
@@ -994,6 +1227,8 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
 }
 
 int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n);
+static int table_build(halo_ctx *ctx);
+static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n);
 
 struct StreamGuard {  // the launch macro uses ctx->stream
     halo_ctx *ctx;
@@ -1067,12 +1302,16 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         }
     }
     StreamGuard guard(ctx, ctx->streams[slot]);
+    if (!ctx->d_table && table_eligible(ctx, d_bases, members, n)) {
+        int rc = table_build(ctx);
+        if (rc) return rc;
+    }
     // The launch sequence below is fixed for a given (bases, scalars, n, form, window): the second
     // time the same key arrives it is captured into a hipGraph, afterwards one graph launch replaces
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1);
+    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1) + 1048576 * (ctx->table_mode + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     // A graph is kept only while the same key keeps arriving on this slot (the bench loop, the rounds of an open)
     // and while no device memory of this library has been allocated or freed since it was instantiated: replaying
@@ -1116,11 +1355,90 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     return HALO_OK;
 }
 
+// T[w][i] = 2^(20 w) G_i over the whole key, built window by window on the context's first table MSM (one-off: 12 passes of
+// 20 doublings and an inversion per point, ~10 ms at n = 2^20)
+static int table_build(halo_ctx *ctx) {
+    if (ctx->d_table) return HALO_OK;
+    size_t n = ctx->n;
+    alloc_epoch_bump(ctx);
+    if (hipMalloc(&ctx->d_table, (size_t)TBL_W * n * 128) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
+    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p [%p, +%zu)\n", (void *)ctx, (void *)ctx->d_table, (size_t)TBL_W * n * 128);
+    HALO_HIP(hipMemcpyAsync(ctx->d_table, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int w = 1; w < TBL_W; ++w)
+        HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->d_table + (size_t)(w - 1) * n * AFF_STRIDE,
+                    (uint32_t)n, TBL_C, ctx->d_table + (size_t)w * n * AFF_STRIDE);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    return HALO_OK;
+}
+// can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key, large enough that
+// 2^19 buckets are well filled, indices within 31 bits.
+static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n) {
+    if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.count != 1 || members.parts != 1) return false;
+    if (n < ((size_t)1 << 20) || n % 4 != 0 || (size_t)TBL_W * ctx->n >= ((size_t)1 << 31)) return false;
+    return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
+}
+static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
+    size_t entries = (size_t)TBL_W * n;
+    if (n > ws.cap_n || entries > ws.cap_sorted || TBL_B > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+    if (!ws.d_fine16) {
+        alloc_epoch_bump(ctx);
+        HALO_HIP(hipMalloc(&ws.d_fine16, ws.cap_sorted * 2));
+    }
+    hipStream_t s = ctx->stream;
+    uint32_t base_off = (uint32_t)((d_bases - ctx->d_bases) / AFF_STRIDE);
+    uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * 13 n bytes <= 2 * 32 n
+    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, mont ? 1 : 0, (uint32_t)n, d_digits,
+                ws.d_meta, ws.d_blockoff);
+    uint32_t nchunks = 256u / TBL_W;  // 19 chunks per window: about one block per CU
+    uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
+    chunk_len = (chunk_len + 3) / 4 * 4;
+    dim3 gridc((unsigned)(TBL_W * nchunks)), b1024(1024), b256(256);
+    uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + (size_t)TBL_W * nchunks * TBL_RANGES;  // 247 * 512 + 513 words <= cap_hist
+    uint32_t kmax = KMAX;
+    HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist);
+    uint32_t *rtotal = cstart + TBL_RANGES + 1;
+    HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(TBL_RANGES), b256, 0, chist, (uint32_t)(TBL_W * nchunks), rtotal);
+    HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(TBL_RANGES), 0, rtotal, cstart);
+    HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
+                (uint32_t)ctx->n, base_off, ws.d_presort, ws.d_fine16);
+    HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(TBL_RANGES), b1024, FINE_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, ws.d_counts,
+                ws.d_starts, ws.d_ntask, ws.d_sorted);
+    uint32_t total = TBL_B, nblocks = (total + 4095) / 4096;
+    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, total, ws.d_toff, ws.d_tblockoff);
+    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
+    size_t max_tasks = (size_t)total + entries / kmax + 1;
+    if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
+    dim3 gridt((unsigned)((max_tasks + 255) / 256));
+    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, total, kmax, ws.d_meta,
+                ws.d_task_g, ws.d_biglist);
+    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff,
+                ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
+                total, 512u, ws.d_buckets);
+    // window sums: the 2^19 buckets as 16 virtual windows of 2^15 (8 buckets per lane, 64 segments of 512 buckets each)
+    uint32_t L = 8, nseg = 64;
+    if (ctx->reduce_span == 16 || ctx->reduce_span == 32 || ctx->reduce_span == 64) { L = (uint32_t)ctx->reduce_span; nseg = 512 / L; }
+    int logL = 0;
+    while ((1u << logL) < L) logL++;
+    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(TBL_VW * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, 32768u, L, logL,
+                nseg, ws.d_seg);
+    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3(TBL_VW), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum, ws.d_winsum + 12 * TBL_VW);
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)2 * TBL_VW * 96, hipMemcpyDeviceToHost, s));
+    MsmPlan p;
+    p.c = TBL_C; p.W = TBL_W; p.B = TBL_B; p.batch = 1; p.w0 = 0; p.w1 = TBL_W; p.table_vw = (int)TBL_VW;
+    ws.plan = p;
+    return HALO_OK;
+}
+
 // the launch sequence proper (recorded into a graph when the stream is capturing); sets ws.plan.
 // Wt = W * batch windows go through the sort / accumulate / reduce kernels as if they belonged to one MSM;
 // only the recode (one scalar array per member) and the scatter (one base offset per member) know better.
 int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
+    if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members.scalars[0], mont, n);
     MsmPlan p = msm_plan(n, ctx->window_bits);
     p.batch = members.count;
     p.w0 = p.W * members.part / members.parts;
@@ -1222,7 +1540,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(Wt * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
-    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)Wt), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum);
+    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)Wt), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum, (uint64_t *)nullptr);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
     ws.plan = p;
@@ -1249,6 +1567,19 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
     MsmPlan p = ws.plan;
     for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
     if (p.W == 0) return;
+    if (p.table_vw > 0) {
+        // virtual window v holds the buckets v 2^15 + 1 .. (v + 1) 2^15: sum_v [ T_v + v 2^15 S_v ]
+        int V = p.table_vw;
+        host::Point acc = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
+        for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * (size_t)v);
+        for (int v = V - 1; v >= 1; --v) {  // tot = sum_v v S_v by running sums
+            run = run + host::Point::load(ws.h_winsum + 12 * (size_t)(V + v));
+            tot = tot + run;
+        }
+        for (int k = 0; k < 15 && !tot.is_inf(); ++k) tot = tot.dbl();
+        out[0] = acc + tot;
+        return;
+    }
     int Wm = p.w1 - p.w0;
     for (int b = 0; b < count; ++b) {
         host::Point acc = host::Point::infinity();
