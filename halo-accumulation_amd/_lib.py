@@ -85,6 +85,8 @@ _SIGS = {
     "halo_pcdl_open_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_pcdl_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_pcdl_succinct_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p]),
+    "halo_pcdl_succinct_check_batch": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
+    "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_acc_prover": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_verifier": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]),
@@ -337,6 +339,9 @@ class Context:
 
     def set_sort_mode(self, mode):
         check(self.lib.halo_set_sort_mode(self.h, mode))
+
+    def set_batch_verify(self, on):
+        check(self.lib.halo_set_batch_verify(self.h, int(on)))
 
     def set_fold_levels(self, levels):
         check(self.lib.halo_set_fold_levels(self.h, levels))

@@ -268,6 +268,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_tmp_c);
     (void)hipFree(ctx->d_poly);
     (void)hipFree(ctx->d_poly2);
+    (void)hipFree(ctx->d_verify);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
     delete ctx;
@@ -917,6 +918,11 @@ int halo_set_table_mode(halo_ctx *ctx, int mode) {
 int halo_set_small_path(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
     ctx->small_path = mode;
+    return HALO_OK;
+}
+int halo_set_batch_verify(halo_ctx *ctx, int on) {
+    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
+    ctx->batch_verify = on != 0;
     return HALO_OK;
 }
 int halo_set_fold_levels(halo_ctx *ctx, int levels) {

@@ -209,11 +209,14 @@ struct halo_ctx {
     int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
+    bool batch_verify = true;              // succinct checks of >= 64 instances in two device launches (else a host thread pool)
     int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
+    uint64_t *d_verify = nullptr;  // staging of the batched verifier (points, scalars, challenges, results), grown on demand
+    size_t verify_words = 0;
     // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover
     uint64_t *d_poly = nullptr, *d_poly2 = nullptr;
     halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker)
@@ -288,6 +291,9 @@ int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host
 // d_out[k] (+)= scale * prod_{bit i of k} xis[lg_n - i]
 int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr &scale, bool accumulate, uint64_t *d_out);
 int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out);
+// m polynomials h_i at their own points z_i; m sums of K scalar multiples (canonical scalars, affine points) -> m Jacobian points
+int h_eval_each(halo_ctx *ctx, const uint64_t *d_xis, const uint64_t *d_zs, size_t m, size_t lg_n, uint64_t *d_out);
+int batch_small_msm(halo_ctx *ctx, const uint64_t *d_points, const uint64_t *d_scalars, size_t m, size_t K, uint64_t *d_out);
 // SplitMix64 stream -> n Montgomery scalars (element i = draws 4i+1..4i+4 after state0)
 int rng_scalars_dev(halo_ctx *ctx, uint64_t state0, size_t n, uint64_t *d_out);
 int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, uint64_t *d_out);

@@ -323,6 +323,63 @@ __global__ __launch_bounds__(256) void k_h_eval(const uint64_t *__restrict__ xis
 }
 
 
+// HPoly::eval for m polynomials, each at its own point (the m succinct checks of acc.rs:158-170 have their own z_i)
+__global__ __launch_bounds__(256) void k_h_eval_z(const uint64_t *__restrict__ xis, const uint64_t *__restrict__ zs, uint32_t m, int lg_n,
+                                                  uint64_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t *x = xis + 4 * (size_t)i * (size_t)(lg_n + 1);
+    Fe z = fe_load(zs + 4 * (size_t)i), one = fe_one<FrCfg>();
+    Fe v = fe_add<FrCfg>(one, fe_mul<FrCfg>(fe_load(x + 4 * (size_t)lg_n), z));
+    Fe zi = z;
+#pragma unroll 1
+    for (int k = 1; k < lg_n; k++) {
+        zi = fe_sqr<FrCfg>(zi);
+        v = fe_mul<FrCfg>(v, fe_add<FrCfg>(one, fe_mul<FrCfg>(fe_load(x + 4 * (size_t)(lg_n - k)), zi)));
+    }
+    fe_store(out + 4 * (size_t)i, v);
+}
+
+// ------------------------------------------------------------------ batched verifier relation
+// m independent sums of K <= 64 scalar multiples each (the 2 lg n + 2 terms of one pcdl::succinct_check, pcdl.rs:288-310):
+// one wave per sum, one lane per term.  Every lane runs the same 256-step ladder (double, add, keep the sum if the bit is
+// set -- no divergence although the scalars differ), then the wave folds its lanes with a shuffle tree.
+// points: m x K x 8 words (arkworks affine, (0, 0) = infinity); scalars: m x K x 4 words, CANONICAL (not Montgomery).
+__global__ __launch_bounds__(64) void k_batch_small_msm(const uint64_t *__restrict__ points, const uint64_t *__restrict__ scalars, uint32_t K,
+                                                        uint64_t *__restrict__ out) {
+    uint32_t inst = blockIdx.x, lane = threadIdx.x;
+    bool live = lane < K;
+    size_t t = (size_t)inst * K + (live ? lane : 0);
+    AffN p = live ? aff_from_words(points + 8 * t) : aff_inf();
+    Fe k = fe_load(scalars + 4 * t);
+    JacN acc = jac_inf();
+#pragma unroll 1
+    for (int limb = 7; limb >= 0; limb--) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) word = (q == limb) ? k.v[q] : word;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = jac_dbl(acc);
+            JacN s = jac_madd(acc, p);
+            bool take = live && ((word >> bit) & 1u);
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                acc.x.v[i] = take ? s.x.v[i] : acc.x.v[i];
+                acc.y.v[i] = take ? s.y.v[i] : acc.y.v[i];
+                acc.z.v[i] = take ? s.z.v[i] : acc.z.v[i];
+            }
+        }
+    }
+    XyzzN x = jac_to_xyzz(acc);
+#pragma unroll 1
+    for (int off = 32; off >= 1; off >>= 1) {
+        XyzzN o = xyzz_shfl(x, (int)((lane + off) & 63));
+        if ((int)lane < off) xyzz_add(x, o);
+    }
+    if (lane == 0) xyzz_store_jac_words(out + 12 * (size_t)inst, x);
+}
+
 // ------------------------------------------------------------------ input generator / polynomial helpers
 // SplitMix64 is counter based: draw k of a stream with state s0 is mix(s0 + k*gamma), so the
 // scalars of `PallasPoly::rand` (pcdl.rs:141) can be produced in parallel, bit-identical to a
@@ -573,6 +630,20 @@ int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr
 int h_eval_batch(halo_ctx *ctx, const uint64_t *d_xis, size_t m, size_t lg_n, const host::Fr &z, uint64_t *d_out) {
     if (m == 0) return HALO_OK;
     HALO_LAUNCH(ctx, "k_h_eval", k_h_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_xis, (uint32_t)m, (int)lg_n, to_arg(z), d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+int h_eval_each(halo_ctx *ctx, const uint64_t *d_xis, const uint64_t *d_zs, size_t m, size_t lg_n, uint64_t *d_out) {
+    if (m == 0) return HALO_OK;
+    HALO_LAUNCH(ctx, "k_h_eval_z", k_h_eval_z, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_xis, d_zs, (uint32_t)m, (int)lg_n, d_out);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int batch_small_msm(halo_ctx *ctx, const uint64_t *d_points, const uint64_t *d_scalars, size_t m, size_t K, uint64_t *d_out) {
+    if (m == 0) return HALO_OK;
+    if (K == 0 || K > 64) { set_error("batch_small_msm: 1..64 terms per sum"); return HALO_E_ARG; }
+    HALO_LAUNCH(ctx, "k_batch_small_msm", k_batch_small_msm, dim3((unsigned)m), dim3(64), 0, d_points, d_scalars, (uint32_t)K, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

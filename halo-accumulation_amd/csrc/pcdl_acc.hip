@@ -7,6 +7,7 @@
 // What stays on the host, exactly as in the reference: Fiat-Shamir hashing (rho_0!/rho_1!),
 // challenge inversion, the O(lg n) succinct check and the struct packing.
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -190,7 +191,8 @@ struct SuccinctState {
     Point C_prime, Hp, U;
     std::vector<Fr> xis;
 };
-static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c, SuccinctState *st) {
+static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c, SuccinctState *st,
+                               bool need_hp = true) {
     uint64_t *proof = const_cast<uint64_t *>(proof_c);
     size_t n = d + 1;
     if (!is_pow2(n)) return fail_reject("d+1 is not a power of 2!");
@@ -212,7 +214,7 @@ static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr
     }
     st->xis.assign(lg_n + 1, Fr::zero());
     st->xis[0] = rho0_C_z_v(st->C_prime, z, v);
-    st->Hp = pp.H.mul(st->xis[0]);
+    if (need_hp) st->Hp = pp.H.mul(st->xis[0]);  // the batched relation multiplies H by (v - v') xi_0 instead
     for (size_t i = 0; i < lg_n; ++i) {
         st->xis[i + 1] = rho0_xi_L_R(st->xis[i], Point::load(pf_L(proof, i)), Point::load(pf_R(proof, lg_n, i)));
         if (st->xis[i + 1].is_zero()) return fail_reject("challenge is zero");
@@ -262,6 +264,105 @@ static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr
     if (rc) return rc;
     *xis_out = std::move(st.xis);
     *U_out = st.U;
+    return HALO_OK;
+}
+
+// ------------------------------------------------------------------ batched succinct checks (acc.rs:158-170)
+// m instances at once: the transcripts (hashes, C') are computed by a bounded pool of host threads, then ONE launch evaluates
+// the m polynomials h_i at their own z_i (k_h_eval_z) and ONE launch computes the m relations (k_batch_small_msm):
+//     C'_i + sum_j (xi_j^-1 L_j + xi_j R_j) + (v_i - c_i h_i(z_i)) xi_0 H - c_i U_i  ==  0        (pcdl.rs:288-310)
+// as 2 lg n + 2 scalar multiples per instance, compared with -C'_i on the host.  Per-instance outcome equals the host path's.
+constexpr size_t kBatchVerifyMin = 64;  // below this the host pool is faster than a 256-step device ladder (~2 ms)
+static void pool_run(size_t m, const std::function<void(size_t)> &fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = hw ? hw : 4;
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads > m) nthreads = m;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < m;) fn(i); };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nthreads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+static int verify_staging(halo_ctx *ctx, size_t words) {
+    if (words <= ctx->verify_words) return HALO_OK;
+    alloc_epoch_bump(ctx);
+    (void)hipFree(ctx->d_verify);
+    ctx->d_verify = nullptr;
+    ctx->verify_words = 0;
+    HALO_HIP(hipMalloc(&ctx->d_verify, words * 8));
+    ctx->verify_words = words;
+    return HALO_OK;
+}
+struct BatchCheck { int rc = HALO_OK; std::string err; SuccinctState st; };
+// instances: m blobs at stride instance_words(lg(d+1)); res[i].rc / .err / .st filled; returns a device / argument error only
+static int succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t m, std::vector<BatchCheck> &res) {
+    size_t lg = ilog2(d + 1), iw = instance_words(lg), K = 2 * lg + 2;
+    res.assign(m, BatchCheck());
+    if (K > 64) { set_error("batched succinct check: lg n too large"); return HALO_E_ARG; }
+    pool_run(m, [&](size_t i) {
+        const uint64_t *q = qs + i * iw;
+        res[i].rc = succinct_challenges(ctx, Point::load(q), (size_t)q[12], Fr::load(q + 13), Fr::load(q + 17), q + 21, &res[i].st, false);
+        if (res[i].rc) res[i].err = halo_last_error();
+    });
+    // staging layout (words): xis m (lg+1) 4 | zs m 4 | hz m 4 | points m K 8 | scalars m K 4 | out m 12
+    size_t o_xis = 0, o_zs = o_xis + m * (lg + 1) * 4, o_hz = o_zs + m * 4, o_pts = o_hz + m * 4, o_sc = o_pts + m * K * 8, o_out = o_sc + m * K * 4,
+           total = o_out + m * 12;
+    int rc = verify_staging(ctx, total);
+    if (rc) return rc;
+    std::vector<uint64_t> host(total, 0);
+    for (size_t i = 0; i < m; ++i) {
+        if (res[i].rc) continue;  // a rejected transcript: its (zero) rows are computed and ignored
+        for (size_t k = 0; k <= lg; ++k) res[i].st.xis[k].store(&host[o_xis + (i * (lg + 1) + k) * 4]);
+        std::memcpy(&host[o_zs + 4 * i], qs + i * iw + 13, 32);
+    }
+    HALO_HIP(hipMemcpyAsync(ctx->d_verify, host.data(), (o_hz) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = h_eval_each(ctx, ctx->d_verify + o_xis, ctx->d_verify + o_zs, m, lg, ctx->d_verify + o_hz);
+    if (rc) return rc;
+    HALO_HIP(hipMemcpyAsync(&host[o_hz], ctx->d_verify + o_hz, m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    const PublicPoints &pp = public_points();
+    host::Affine Ha = pp.H.to_affine();
+    pool_run(m, [&](size_t i) {
+        if (res[i].rc) return;
+        const uint64_t *q = qs + i * iw;
+        uint64_t *proof = const_cast<uint64_t *>(q + 21);
+        const SuccinctState &st = res[i].st;
+        uint64_t *pts = &host[o_pts + i * K * 8], *sc = &host[o_sc + i * K * 4];
+        auto put_point = [&](size_t slot, const Point &p) {
+            host::Affine a = p.to_affine();
+            if (!a.inf) { a.x.store(pts + 8 * slot); a.y.store(pts + 8 * slot + 4); }
+        };
+        // challenge inverses with one inversion (Montgomery's trick)
+        std::vector<Fr> pref(lg + 1, Fr::one()), inv(lg + 1);
+        for (size_t j = 0; j < lg; ++j) pref[j + 1] = pref[j] * st.xis[j + 1];
+        Fr run = lg ? pref[lg].inv() : Fr::one();
+        for (size_t j = lg; j-- > 0;) { inv[j + 1] = run * pref[j]; run = run * st.xis[j + 1]; }
+        for (size_t j = 0; j < lg; ++j) {
+            put_point(j, Point::load(pf_L(proof, j)));
+            inv[j + 1].from_mont().store(sc + 4 * j);
+            put_point(lg + j, Point::load(pf_R(proof, lg, j)));
+            st.xis[j + 1].from_mont().store(sc + 4 * (lg + j));
+        }
+        Fr c = Fr::load(pf_c(proof, lg)), v = Fr::load(q + 17), hz = Fr::load(&host[o_hz + 4 * i]);
+        Ha.x.store(pts + 8 * (2 * lg)); Ha.y.store(pts + 8 * (2 * lg) + 4);
+        ((v - c * hz) * st.xis[0]).from_mont().store(sc + 4 * (2 * lg));      // (v - v') xi_0 on H: the two H' terms of :288 and :307
+        put_point(2 * lg + 1, st.U);
+        (-c).from_mont().store(sc + 4 * (2 * lg + 1));
+    });
+    HALO_HIP(hipMemcpyAsync(ctx->d_verify + o_pts, &host[o_pts], (o_out - o_pts) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = batch_small_msm(ctx, ctx->d_verify + o_pts, ctx->d_verify + o_sc, m, K, ctx->d_verify + o_out);
+    if (rc) return rc;
+    HALO_HIP(hipMemcpyAsync(&host[o_out], ctx->d_verify + o_out, m * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < m; ++i) {
+        if (res[i].rc) continue;
+        if (Point::load(&host[o_out + 12 * i]) != -res[i].st.C_prime) {
+            res[i].rc = HALO_E_REJECT;
+            res[i].err = "C_(log_n) != CM.Commit_Sigma(c || v')";  // :307-310
+        }
+    }
     return HALO_OK;
 }
 
@@ -339,19 +440,20 @@ static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t
                                         &res[i].U);  // :164
         if (res[i].rc) res[i].err = halo_last_error();
     };
-    if (m <= 1) {
+    if (m >= kBatchVerifyMin && ctx->batch_verify) {  // the relations of all instances in two launches
+        std::vector<BatchCheck> bres;
+        rc = succinct_check_batch(ctx, d, qs, m, bres);
+        if (rc) return rc;
+        for (size_t i = 0; i < m; ++i) {
+            res[i].rc = bres[i].rc;
+            res[i].err = std::move(bres[i].err);
+            res[i].xis = std::move(bres[i].st.xis);
+            res[i].U = bres[i].st.U;
+        }
+    } else if (m <= 1) {
         for (size_t i = 0; i < m; ++i) run_one(i);
     } else {  // a bounded pool: at most 16 host threads pull instances off a shared counter
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t nthreads = hw ? hw : 4;
-        if (nthreads > 16) nthreads = 16;
-        if (nthreads > m) nthreads = m;
-        std::atomic<size_t> next{0};
-        auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < m;) run_one(i); };
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nthreads; ++t) th.emplace_back(worker);
-        worker();
-        for (auto &t : th) t.join();
+        pool_run(m, run_one);
     }
     for (size_t i = 0; i < m; ++i) {
         if (res[i].rc) { set_error(res[i].err); return res[i].rc; }
@@ -488,6 +590,41 @@ int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, cons
     if (rc) return rc;
     for (size_t i = 0; i < xis.size(); ++i) xis[i].store(xis_out + 4 * i);
     U.store_normalized(U_out);
+    return HALO_OK;
+}
+
+// m succinct checks at once (instances at stride halo_instance_words(lg(d+1)), all of degree bound d): on the device from
+// 64 instances on, on a pool of host threads below.  status[i] = 0 or HALO_E_REJECT; returns HALO_E_REJECT (message names the
+// first rejected instance) if any was rejected.  xis_out: m x (lg+1) x 4, U_out: m x 12 (both nullable).
+int halo_pcdl_succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *instances, size_t m, uint64_t *xis_out, uint64_t *U_out,
+                                   int *status) {
+    HALO_CTX2(ctx);
+    if (m && !instances) { set_error("succinct_check_batch: null pointer"); return HALO_E_ARG; }
+    if (!is_pow2(d + 1)) return fail_reject("d+1 is not a power of 2!");
+    size_t lg = ilog2(d + 1), iw = instance_words(lg);
+    for (size_t i = 0; i < m; ++i)
+        if ((size_t)(instances + i * iw)[12] != d || (instances + i * iw)[22] != lg) return fail_reject("d_i != d");
+    std::vector<BatchCheck> res;
+    if (m >= kBatchVerifyMin && ctx->batch_verify) {
+        int rc = succinct_check_batch(ctx, d, instances, m, res);
+        if (rc) return rc;
+    } else {
+        res.assign(m, BatchCheck());
+        pool_run(m, [&](size_t i) {
+            const uint64_t *q = instances + i * iw;
+            res[i].rc = succinct_challenges(ctx, Point::load(q), d, Fr::load(q + 13), Fr::load(q + 17), q + 21, &res[i].st);
+            if (!res[i].rc) res[i].rc = succinct_relation(res[i].st, Fr::load(q + 13), Fr::load(q + 17), q + 21);
+            if (res[i].rc) res[i].err = halo_last_error();
+        });
+    }
+    int first = -1;
+    for (size_t i = 0; i < m; ++i) {
+        if (status) status[i] = res[i].rc;
+        if (res[i].rc) { if (first < 0) first = (int)i; continue; }
+        if (xis_out) for (size_t k = 0; k <= lg; ++k) res[i].st.xis[k].store(xis_out + ((lg + 1) * i + k) * 4);
+        if (U_out) res[i].st.U.store_normalized(U_out + 12 * i);
+    }
+    if (first >= 0) { set_error("instance " + std::to_string(first) + ": " + res[first].err); return res[first].rc; }
     return HALO_OK;
 }
 

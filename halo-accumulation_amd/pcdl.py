@@ -63,6 +63,22 @@ def succinct_check(ctx, Cm, d, z, v, pi):
     return xis, U
 
 
+def succinct_check_batch(ctx, d, instances):
+    """m succinct checks at once -> (xis (m, lg+1, 4), Us (m, 12), status (m,)); raises HaloReject if any instance fails
+    (status then still tells which: use return_status=True semantics through the status array of the exception args)"""
+    qs = np.ascontiguousarray(np.concatenate(instances)) if len(instances) else np.zeros(0, dtype=np.uint64)
+    m, lg = len(instances), max(lg_of(d), 0)
+    xis = np.zeros((m, lg + 1, 4), dtype=np.uint64)
+    Us = np.zeros((m, 12), dtype=np.uint64)
+    status = (C.c_int * max(m, 1))()
+    rc = ctx.lib.halo_pcdl_succinct_check_batch(ctx.h, d, ptr(qs), m, ptr(xis), ptr(Us), status)
+    st = [status[i] for i in range(m)]
+    if rc == _lib.HALO_E_REJECT:
+        raise _lib.HaloReject(ctx.lib.halo_last_error().decode(), st)
+    check(rc)
+    return xis, Us, st
+
+
 def check_proof(ctx, Cm, d, z, v, pi):
     """pcdl::check (pcdl.rs:323-342)"""
     check(ctx.lib.halo_pcdl_check(ctx.h, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(v)), ptr(_a(pi))))

@@ -179,6 +179,12 @@ int halo_pcdl_open_dev(halo_ctx *ctx, uint64_t *rng_state, const void *d_coeffs,
 /* pcdl::succinct_check (pcdl.rs:252-314): xis_out (lg+1) x 4, U_out */
 int halo_pcdl_succinct_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
                              const uint64_t *proof, uint64_t *xis_out, uint64_t U_out[12]);
+/* m succinct checks at once (acc.rs:158-170 runs them in a loop): instances = m Instance blobs of degree bound d.  From 64
+ * instances on the m relations are evaluated in two device launches (h_i(z_i) for all i; the 2 lg n + 2 scalar multiples
+ * of every relation, one wave per instance), the transcripts on a pool of host threads.  status[i] (nullable) = 0 or
+ * HALO_E_REJECT per instance; xis_out m x (lg+1) x 4 and U_out m x 12 (nullable) as halo_pcdl_succinct_check. */
+int halo_pcdl_succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *instances, size_t m, uint64_t *xis_out, uint64_t *U_out,
+                                   int *status);
 /* pcdl::check (pcdl.rs:323-342) */
 int halo_pcdl_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof);
 /* acc::prover / verifier / decider (acc.rs:190-255); instances = m contiguous Instance blobs */
@@ -226,6 +232,8 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 /* IPA tuning: 2 (default) folds G every other round, two halvings at once with one shared doubling chain, the rounds in
  * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */
 int halo_set_fold_levels(halo_ctx *ctx, int levels);
+/* verifier tuning: 1 (default) = succinct checks of >= 64 instances on the device, 0 = always the host thread pool */
+int halo_set_batch_verify(halo_ctx *ctx, int on);
 /* MSM tuning: window bits (0 = automatic) */
 int halo_set_window_bits(halo_ctx *ctx, int c);
 /* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */

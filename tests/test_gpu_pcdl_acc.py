@@ -234,6 +234,97 @@ def test_acc_scheme_matches_oracle(hal, ctx, pp, n, steps):
     orc.acc_decider(pp, acc)
 
 
+def _plain_instance(ctx, seed, d):
+    """an Instance with a non-hiding proof (random_instance always hides)"""
+    from halo_accumulation_amd import pcdl
+    coeffs, s = orc.rng_scalars(seed, d + 1 - (seed % 3))
+    z, _ = orc.rng_scalars(s, 1)
+    Cm = pcdl.commit(ctx, coeffs, d)
+    pi = pcdl.open(ctx, [seed], coeffs, Cm, d, z[0])
+    v = ctx.poly_eval(coeffs, z[0])
+    return np.concatenate([Cm, np.array([d], dtype=np.uint64), z[0], v, pi])
+
+
+@pytest.mark.parametrize("lg", [10, 20])
+def test_succinct_check_batch_64_on_device(hal, lg):
+    """SURVEY 8f-2 / acc.rs:158-170: 64 succinct checks in two device launches (k_h_eval_z, k_batch_small_msm), instance by
+    instance equal to the oracle's pcdl::succinct_check; tampered instances are the ones -- and the only ones -- rejected,
+    exactly as by the host path."""
+    import json, os, time
+    from halo_accumulation_amd import acc as A, pcdl
+    n, m = 1 << lg, 64
+    d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        pp = orc.make_pp(c.read_bases())
+        rng = [0x48414C4F00000006 + lg]
+        qs = [A.random_instance(c, rng, d) if i % 4 else _plain_instance(c, 900 + i, d) for i in range(m)]
+        t0 = time.perf_counter()
+        xis, Us, status = pcdl.succinct_check_batch(c, d, qs)
+        t_dev = time.perf_counter() - t0
+        assert status == [0] * m
+        for i, q in enumerate(qs):
+            xr, Ur = orc.pcdl_succinct_check(pp, q[:12], d, q[13:17], q[17:21], q[21:])
+            assert xis[i].tolist() == xr.tolist() and Us[i].tolist() == Ur.tolist(), i
+        c.set_batch_verify(False)
+        t0 = time.perf_counter()
+        xis2, Us2, status2 = pcdl.succinct_check_batch(c, d, qs)
+        t_host = time.perf_counter() - t0
+        assert xis2.tolist() == xis.tolist() and Us2.tolist() == Us.tolist()
+        # tamper: v of instance 7, c of instance 20, swap L_0 and R_0 of instance 33 (valid points, wrong relation)
+        bad = [q.copy() for q in qs]
+        bad[7][17] ^= 1
+        bad[20][21 + 2 + 24 * lg + 12] ^= 1
+        bad[33][23:35], bad[33][23 + 12 * lg: 35 + 12 * lg] = qs[33][23 + 12 * lg: 35 + 12 * lg].copy(), qs[33][23:35].copy()
+        want = [0] * m
+        for i in (7, 20, 33):
+            want[i] = hal._lib.HALO_E_REJECT
+            with pytest.raises(ValueError):
+                orc.pcdl_succinct_check(pp, bad[i][:12], d, bad[i][13:17], bad[i][17:21], bad[i][21:])
+        for on in (True, False):
+            c.set_batch_verify(on)
+            with pytest.raises(hal._lib.HaloReject) as e:
+                pcdl.succinct_check_batch(c, d, bad)
+            assert e.value.args[1] == want and "instance 7" in e.value.args[0]
+        c.set_batch_verify(True)
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "batch_verify_lg%d.json" % lg), "w") as f:
+            json.dump({"config": "64 succinct checks, n=2^%d" % lg, "device_ms_each": t_dev / m * 1e3, "host_pool_ms_each": t_host / m * 1e3}, f)
+    finally:
+        c.close()
+
+
+def test_acc_with_64_instances_matches_oracle(hal, ctx, pp):
+    """acc::prover / verifier over m = 64 instances at n = 1024 (the common subroutine takes the device-batched succinct
+    checks): accumulator equal to the oracle's, accepted by both verifiers, by the decider, and with the host path."""
+    from halo_accumulation_amd import acc as A
+    n, m = 1024, 64
+    d = n - 1
+    rng, seed = [31], 31
+    qs = []
+    for _ in range(m):
+        q = A.random_instance(ctx, rng, d)
+        q_ref, seed = orc.random_instance(pp, seed, d)
+        assert q.tolist() == q_ref.tolist()
+        qs.append(q)
+    acc = A.prover(ctx, rng, d, qs)
+    acc_ref, seed = orc.acc_prover(pp, seed, d, qs)
+    assert acc.tolist() == acc_ref.tolist() and rng[0] == seed
+    A.verifier(ctx, d, qs, acc)
+    orc.acc_verifier(pp, d, qs, acc)
+    A.decider(ctx, acc)
+    ctx.set_batch_verify(False)
+    try:
+        A.verifier(ctx, d, qs, acc)
+        assert A.prover(ctx, [rng[0] - 0], d, qs) is not None
+    finally:
+        ctx.set_batch_verify(True)
+    bad = [q.copy() for q in qs]; bad[40][17] ^= 1
+    with pytest.raises(ValueError):
+        A.verifier(ctx, d, bad, acc)
+
+
 def test_open_2_17_both_strategies_agree(hal):
     """n = 2^17: one real fold round then no-fold rounds, against folding all the way; the
     verifier (succinct check + U == commit(h)) accepts and the proofs are identical."""
