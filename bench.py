@@ -40,6 +40,8 @@ def main():
                     help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index")
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
+    ap.add_argument("--asdl-steps", type=int, default=8, help="ASDL chain steps (random_instance + prover + verifier, then one decider) at N=1 (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,13 +105,19 @@ def main():
 
     def run_steps(k):
         depth = cfg["depth"]
-        pending = []  # (slot, members)
+        pending = []   # (slot, members)
+        gathers = []   # all-gathers issued and not yet collected: each runs under the launches enqueued after it
+
+        def collect():
+            for j, pt in enumerate(gather.gather_finish(gathers.pop(0))):
+                outs[j] = pt
 
         def finish():
             slot, m = pending.pop(0)
             partials = ctx.msm_dev_batch_end(slot, m)
-            for j, pt in enumerate(gather.gather_batch([partials[j] for j in range(m)])):  # one all-gather per launch
-                outs[j] = pt
+            gathers.append(gather.gather_start([partials[j] for j in range(m)]))  # one all-gather per launch, asynchronous
+            while len(gathers) > 1:
+                collect()
 
         launches = 0
         while k > 0:
@@ -123,6 +131,8 @@ def main():
             k -= m
         while pending:
             finish()
+        while gathers:
+            collect()
 
     def barrier():
         if world > 1 or force_dist:
@@ -131,16 +141,23 @@ def main():
 
     run_steps(3 * args.depth * batch)  # untimed: every slot allocates its workspace and captures its launch graph
     run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    # The timed region is EXACTLY --steps steps between barrier + synchronize; it is repeated until --min-seconds are covered
+    # (a 20-step region lasts 25 ms: one sample says little) and the median repetition is reported, all of them listed.
+    reps = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        if world > 1 or force_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's time
+        reps.append(float(t.item()))
+        if sum(reps) >= args.min_seconds or len(reps) >= 200:
+            break
+    dt = sorted(reps)[len(reps) // 2]
     out = outs[0]
-    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    if world > 1 or force_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
 
     # Kernel durations for the roofline: HIP events on the stream each kernel is launched on, in two
     # extra passes of the same loop right after the timed region (the event brackets need individual
@@ -163,6 +180,16 @@ def main():
     cfg["depth"] = args.depth
     ctx.prof_enable(0)
 
+    # what the collective layer itself reports: backend, ranks, and how many distinct devices they sit on
+    backend_name, world_reported, distinct_gpus, coll_name = "none", 1, 1, "no"
+    if world > 1 or force_dist:
+        backend_name, world_reported = dist.get_backend(), dist.get_world_size()
+        coll_name = "RCCL" if backend_name == "nccl" else backend_name
+        props_me = torch.cuda.get_device_properties(gpu)
+        ident = "%s/%s/%d" % (os.uname().nodename, getattr(props_me, "uuid", props_me.name), gpu)
+        idents = [None] * world_reported
+        dist.all_gather_object(idents, ident)
+        distinct_gpus = len(set(idents))
     result = None
     if rank == 0:
         dom = "k_msm_accumulate" if "k_msm_accumulate" in prof_solo else "k_smsm_accumulate"  # n <= 2^16: the small-MSM pipeline
@@ -172,16 +199,20 @@ def main():
         # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
         # index block or their 1/parts window share on this rank)
         alg_bytes = batch * (96 * (hi - lo) // parts + 64)
-        traffic = None  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (n = 2^20, 1 GPU only)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM-side bytes per launch: PMC counters need a rocprofv3 --pmc pass of their own (tools/evidence.sh), they cannot be
+        # read inside this run -- the figure is STATIC, taken from the committed pass named in traffic_source
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if world == 1 and args.log_n == 20 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["kernels"].get("k_msm_accumulate", {}).get("traffic_bytes_per_launch")
+            pj = json.load(open(pmc))
+            traffic = pj["kernels"].get(dom, {}).get("traffic_bytes_per_launch")
+            traffic_source = "static: profiles/r02_pmc_traffic.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         # VALU view of the same kernel: one mixed XYZZ addition is 1143 v_mad_u64_u32 on the
         # kernel's hot path (counted in the gfx950 ISA), one per point per window; the issue peak is the measured
         # 5.26 cycles per wave-instruction (profiles/r01_microbench_instr_throughput.txt) on 4 SIMDs per CU
         props = torch.cuda.get_device_properties(gpu)
-        plan_w = 16 if args.log_n >= 20 else None
+        plan_w = (13 if world == 1 else 16) if args.log_n >= 20 else None  # fixed-base tables (c = 20) on one GPU, c = 16 window shards on more
         valu = None
         if plan_w and kern_s > 0:
             wave_mads = batch * (hi - lo) * plan_w / parts * 1143 / 64
@@ -191,15 +222,18 @@ def main():
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
             "value": args.steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "timed_region": {"repetitions": len(reps), "reported": "median", "seconds_each": [round(x, 6) for x in reps[:32]]},
             "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
                        "sharding": "single GPU" if world == 1 else
-                                   ("Pippenger windows split over the ranks (key + scalars replicated), RCCL all-gather of 96 B partials" if window_mode
-                                    else "block index shard per rank + RCCL all-gather of 96 B partials"),
+                                   ("Pippenger windows split over the ranks (key + scalars replicated), %s all-gather of 96 B partials" % coll_name if window_mode
+                                    else "block index shard per rank + %s all-gather of 96 B partials" % coll_name),
+                       "collective_backend": backend_name, "world_size": world_reported, "distinct_gpus": distinct_gpus,
                        "msms_per_launch": batch, "launches_in_flight": args.depth,
-                       "window_bits": "auto (16 at n >= 2^20; measured table below, msm.hip msm_plan)"},
+                       "window_bits": "one GPU: 20 with fixed-base tables over the context's key (13 windows, one set of 2^19 buckets); "
+                                      "N > 1: 16 (window shards of the 16-window MSM)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
                          "algorithmic_bytes": alg_bytes, "valu": valu,
                          "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
@@ -209,9 +243,25 @@ def main():
     if world == 1:
         # bit-exactness in the same run + CPU baseline (oracle = single-thread port of the arkworks path)
         gs = ctx.read_bases()
+        cpu_model = "unknown"
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        # the same MSM with the scalars handed over in HOST memory (halo_msm: 32 MiB H2D per MSM at n = 2^20, pageable):
+        # the PCIe-inclusive rate; never `value`
+        sc_host = np.ascontiguousarray(d_sets[0].cpu().numpy().view(np.uint64).reshape(n, 4))
+        ctx.msm(sc_host)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            got_h = ctx.msm(sc_host)
+        h2d_dt = (time.perf_counter() - t0) / 8
+        assert got_h.tolist() == out.tolist()
+        result["end_to_end_host_scalars"] = {"value": 1.0 / h2d_dt, "unit": "MSM/s", "ms": h2d_dt * 1e3,
+                                             "note": "halo_msm: scalars copied from pageable host memory each call, one MSM in flight"}
         if args.cpu_msms > 0:
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
-            sc_all = np.ascontiguousarray(d_sets[0].cpu().numpy().view(np.uint64).reshape(n, 4))
+            sc_all = sc_host
             assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
             t0 = time.perf_counter()
             for _ in range(args.cpu_msms):
@@ -219,10 +269,14 @@ def main():
             cpu_dt = (time.perf_counter() - t0) / args.cpu_msms
             assert out.tolist() == want.tolist(), "GPU MSM differs from the CPU restatement"
             result["bit_exact_vs_cpu"] = True
-            # the same port on many cores: independent MSMs, one per thread (ctypes releases the GIL); a reported
-            # figure next to the single-thread one, which is how the reference runs
+            # the same port on all the host cores this process may use: independent MSMs, one per thread (ctypes releases the
+            # GIL); a reported figure next to the single-thread one, which is how the reference runs
             import threading
-            T = max(1, min(16, os.cpu_count() or 1))  # the CPU share of a one-GPU box
+            try:
+                T = len(os.sched_getaffinity(0))
+            except Exception:
+                T = os.cpu_count() or 1
+            T = max(1, min(T, 64))
             box = [None] * T
 
             def one(k):
@@ -236,35 +290,73 @@ def main():
                 th.join()
             par_dt = time.perf_counter() - t0
             assert all(b.tolist() == want.tolist() for b in box)
-            result["cpu_baseline_all_threads"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port",
-                                                   "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
-            result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port",
+            result["cpu_baseline_all_cores"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port", "cpu_model": cpu_model,
+                                                "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
+            result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
                                       "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
                                       "host_cpus": os.cpu_count()}
         if args.open_steps > 0:
+            # BASELINE configs[2]: pcdl::open + check at the same n.  Compute-only = the polynomial already resident in device
+            # memory (halo_pcdl_open_dev); end-to-end = coefficients handed over in pageable host memory (halo_pcdl_open).
             d = n - 1
             d_co = torch.empty((n + 2) * 4, dtype=torch.int64, device=dev)
             ctx.rng_scalars_dev(0x48414C4F00000003, n + 2, d_co.data_ptr())  # seed ...03: n coefficients, then z, w
             co = np.ascontiguousarray(d_co.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
             coeffs, zw = np.ascontiguousarray(co[:n]), np.ascontiguousarray(co[n:])
-            C = pcdl.commit(ctx, coeffs, d)
-            pi = pcdl.open(ctx, [1], coeffs, C, d, zw[0])  # warm-up
+            C = pcdl.commit_dev(ctx, d_co.data_ptr(), n, d)
+            assert C.tolist() == pcdl.commit(ctx, coeffs, d).tolist()
+            pi = pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])  # warm-up
             v = ctx.poly_eval(coeffs, zw[0])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.open_steps):
-                pi = pcdl.open(ctx, [1], coeffs, C, d, zw[0])
-                pcdl.check_proof(ctx, C, d, zw[0], v, pi)
-            torch.cuda.synchronize()
-            odt = (time.perf_counter() - t0) / args.open_steps
-            ctx.prof_enable(2); ctx.prof_reset()  # one more open with event brackets around the fold kernel
-            pcdl.open(ctx, [1], coeffs, C, d, zw[0])
+
+            def timed(fn):
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(args.open_steps):
+                    t0 = time.perf_counter()
+                    p_ = fn()
+                    pcdl.check_proof(ctx, C, d, zw[0], v, p_)
+                    ts.append(time.perf_counter() - t0)
+                return sorted(ts)[len(ts) // 2], p_
+
+            odt, pi = timed(lambda: pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0]))
+            hdt, pi_h = timed(lambda: pcdl.open(ctx, [1], coeffs, C, d, zw[0]))
+            assert pi.tolist() == pi_h.tolist()
+            hid_dt, _ = timed(lambda: pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0]))  # (re-measure after the host path)
+            ctx.prof_enable(2); ctx.prof_reset()  # one more open with event brackets around the fold kernels
+            pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
             prof = ctx.prof()
             ctx.prof_enable(0)
-            fold_ms = prof.get("k_fold_points", (0.0, 0))[0]
+            fold_ms = sum(ms for k, (ms, cnt) in prof.items() if k.startswith("k_fold_points"))
+            odt = min(odt, hid_dt)
             result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False,
                                           "algorithmic_bytes": 480 * n, "hbm_roofline_frac": (480 * n / odt) / (HBM_PEAK_GBS * 1e9),
-                                          "k_fold_points_ms_per_open": fold_ms}
+                                          "k_fold_points_ms_per_open": fold_ms,
+                                          "end_to_end_host_polynomial_ms": hdt * 1e3,
+                                          "note": "value: polynomial resident in device memory (halo_pcdl_open_dev); end_to_end: 32 MiB of "
+                                                  "coefficients copied from pageable host memory per open (halo_pcdl_open); median of %d" % args.open_steps}
+        if args.asdl_steps > 0:
+            # BASELINE configs[3], the shape of benches/acc.rs:64-98 on a short chain: K x (random_instance + prover), K x verifier,
+            # one decider (tests/test_gpu_pcdl_acc.py runs the full 64-step chain)
+            from halo_accumulation_amd import acc as A
+            d = n - 1
+            rng_a = [0x48414C4F00000004]
+            accs, qss, acc_ = [], [], None
+            t0 = time.perf_counter()
+            for _ in range(args.asdl_steps):
+                q = A.random_instance(ctx, rng_a, d)
+                qs = [q] if acc_ is None else [A.instance_from_accumulator(ctx, acc_, d), q]
+                acc_ = A.prover(ctx, rng_a, d, qs)
+                accs.append(acc_); qss.append(qs)
+            t_chain = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for a_, qs in zip(accs, qss):
+                A.verifier(ctx, d, qs, a_)
+            t_ver = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            A.decider(ctx, accs[-1])
+            t_dec = time.perf_counter() - t0
+            result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_chain / args.asdl_steps * 1e3,
+                                    "verifier_ms_each": t_ver / args.asdl_steps * 1e3, "decider_ms": t_dec * 1e3, "all_accepted": True}
     if world > 1 and rank == 0:
         # cross-check of the sharded results: the same MSMs, unsharded, on this rank's GPU alone
         full = ctx if window_mode else h._lib.Context(urs_n=n, first_index=2, device=gpu)

@@ -50,16 +50,32 @@ class ShardedMsm:
     def gather_batch(self, parts):
         """All-gather k local partials (list of (12,) arrays) with ONE collective and combine each:
         fewer, larger collectives -- the exchange is latency-bound (k * 96 bytes per rank)."""
+        return self.gather_finish(self.gather_start(parts))
+
+    def gather_start(self, parts):
+        """Issue the all-gather of k local partials without waiting for it (async_op): the caller enqueues its next launch
+        and collects the result with gather_finish -- the collective runs under that launch."""
         k = len(parts)
         if k == 0:
-            return []
+            return (0, None, None, None)
         local = np.ascontiguousarray(np.stack(parts), dtype=np.uint64)
         if self.world == 1 and not self.always_collective:
-            return [local[i] for i in range(k)]
+            return (k, local, None, None)
         torch = self.torch
-        send = torch.from_numpy(local.view(np.int64).reshape(-1)).to(self.device)
+        send = torch.from_numpy(local.view(np.int64).reshape(-1))
+        if self.device.type != "cpu":
+            send = send.pin_memory().to(self.device, non_blocking=True)
         recv = torch.empty(self.world * k * 12, dtype=torch.int64, device=self.device)
-        self.dist.all_gather_into_tensor(recv, send)
+        work = self.dist.all_gather_into_tensor(recv, send, async_op=True)
+        return (k, send, recv, work)
+
+    def gather_finish(self, handle):
+        k, send, recv, work = handle
+        if k == 0:
+            return []
+        if work is None:
+            return [send[i] for i in range(k)]
+        work.wait()
         pts = recv.cpu().numpy().view(np.uint64).reshape(self.world, k, 12)
         return [self.sum_fn(np.ascontiguousarray(pts[:, i, :])) for i in range(k)]
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_emits_contract_json():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--steps", "6", "--warmup", "1",
-                          "--cpu-msms", "1", "--open-steps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-msms", "1", "--open-steps", "1", "--asdl-steps", "2", "--min-seconds", "0.05"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly ONE line on stdout"
@@ -33,7 +33,10 @@ def test_bench_emits_contract_json():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0
     assert r["bit_exact_vs_cpu"] is True
-    assert r["pcdl_open_check"]["value"] > 0
+    assert r["pcdl_open_check"]["value"] > 0 and r["pcdl_open_check"]["end_to_end_host_polynomial_ms"] > 0
+    assert r["timed_region"]["repetitions"] >= 1 and r["timed_region"]["reported"] == "median"
+    assert r["end_to_end_host_scalars"]["value"] > 0 and r["asdl_chain"]["all_accepted"] is True
+    assert "cpu_model" in cb and r["cpu_baseline_all_cores"]["cores"] >= 1
 
 
 def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():

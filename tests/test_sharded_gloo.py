@@ -1,4 +1,4 @@
-"""N > 1 path of the sharded MSM on CPU: world_size 2 (and 3, uneven shards) over gloo.
+"""N > 1 path of the sharded MSM on CPU: world_size 2, 3 (uneven shards) and 8 (the node size) over gloo.
 
 The per-rank Pippenger runs on the GPU in production; here the partial comes from the oracle so
 that the sharding, the all-gather and the fixed-order combine are exercised without a device."""
@@ -40,6 +40,11 @@ def _worker(rank, world, port, n, q):
     batch = msm.gather_batch([part, inf, part])
     assert batch[0].tolist() == out.tolist() == batch[2].tolist()
     assert orc.point_canonical(batch[1]) is None
+    # asynchronous form: two collectives in flight, finished in issue order (bench.py keeps one under the next launch)
+    h1, h2 = msm.gather_start([part]), msm.gather_start([inf, part])
+    assert msm.gather_finish(h1)[0].tolist() == out.tolist()
+    r2 = msm.gather_finish(h2)
+    assert orc.point_canonical(r2[0]) is None and r2[1].tolist() == out.tolist()
     q.put((rank, out.tolist(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
@@ -68,7 +73,7 @@ def _window_worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_window_sharded_msm_gloo(world):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
@@ -90,7 +95,7 @@ def test_window_sharded_msm_gloo(world):
         assert out == want, "rank %d disagrees" % rank
 
 
-@pytest.mark.parametrize("world,n", [(2, 256), (3, 101)])
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 101), (8, 203)])
 def test_sharded_msm_gloo(world, n):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
