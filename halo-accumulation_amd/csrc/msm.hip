@@ -818,8 +818,9 @@ HALO_DEV XyzzN bucket_value(const uint32_t *__restrict__ partial, const uint32_t
 // first bucket).  Returns in lane 0: S_tot = sum_l S_l and T_tot = sum_l (T_l + l * 2^k * S_l).
 // `park` (36 words per lane, LDS) holds T while S is scanned: with S, T, a shuffled copy and the temporaries of an
 // addition live together the kernel needed 258 VGPRs, i.e. one wave per SIMD and no room next to a 256-register
-// wave of k_msm_accumulate; forcing 256 made it spill (and a kernel with scratch inside a replayed hipGraph is
-// what faulted on ROCm 7.2 once the queue's scratch had been re-assigned).
+// wave of k_msm_accumulate; forcing 256 made it spill, and that spill -- scratch inside a replayed hipGraph after the
+// queue's scratch had been re-assigned -- is what faulted on ROCm 7.2 in round 1 (build gate:
+// csrc/check_resources.py).
 HALO_DEV void wave_weighted_sum(XyzzN &S, XyzzN &T, int k, uint32_t *park, int live = 64) {
     int lane = threadIdx.x & 63;
     {
@@ -1313,12 +1314,12 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     MsmWorkspace::GraphKey key;
     key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1) + 1048576 * (ctx->table_mode + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
-    // A graph is kept only while the same key keeps arriving on this slot (the bench loop, the rounds of an open)
-    // and while no device memory of this library has been allocated or freed since it was instantiated: replaying
-    // an old graph after other work -- another context re-allocating its workspaces, the caller freeing the scalar
-    // buffer and getting the same address back for a new one -- ended in a GPU memory fault on ROCm 7.2
-    // (tests/test_gpu_parity.py: pipelined slots -> randomised configurations -> batch_2_18, in that order).
-    // Callers must keep the scalar buffers of a repeated launch allocated between the repetitions.
+    // A graph is kept while the same key keeps arriving on this slot and this context has not allocated or freed device
+    // memory since it was instantiated (its own workspaces, table, IPA buffers: first use only -- the opens of a loop
+    // allocate nothing, so their graphs survive).  A replay launches exactly the kernels, grids and arguments a fresh
+    // enqueue with this key would.  The GPU memory fault of round 1 ("graph REPLAY ... n=262144") was a kernel with
+    // SCRATCH inside a replayed graph (k_msm_reduce1: 256 VGPRs, 12 B/lane of spill) after the queue's scratch had been
+    // re-assigned -- not a stale pointer: csrc/check_resources.py now fails the build if any kernel uses scratch.
     if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != ctx->alloc_epoch)) {
         (void)hipGraphExecDestroy(ws.graph_exec);
         ws.graph_exec = nullptr;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence on the GPU box: parity tests, bench line, rocprofv3 kernel stats (4 launches in flight, 1 in
-# flight, with open+check), PMC traffic passes, N>1 rehearsal (gloo ranks sharing the one GPU), ASDL chain.
+# flight, with open+check), PMC traffic passes, N>1 rehearsals (gloo ranks sharing the one GPU), ASDL chain.
 # Usage (from the repo root, on the GPU box): bash tools/evidence.sh ; everything lands in gpurun_out/ev/
 set -o pipefail
 OUT=gpurun_out/ev
@@ -10,17 +10,20 @@ step() { echo "== $1" | tee -a $OUT/progress.txt; }
 step pytest;  timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1 || { tail -5 $OUT/pytest_gpu.txt; exit 1; }
 tail -1 $OUT/pytest_gpu.txt
 step bench;   timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-step prof_d4; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d4 -- python bench.py --steps 40 --warmup 4 --cpu-msms 0 --open-steps 0 > $OUT/prof_d4.log 2>&1 || exit 1
-step prof_d1; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1 -- python bench.py --steps 40 --warmup 4 --depth 1 --cpu-msms 0 --open-steps 0 > $OUT/prof_d1.log 2>&1 || exit 1
-step prof_open; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_open -- python bench.py --steps 8 --warmup 2 --cpu-msms 0 --open-steps 2 > $OUT/prof_open.log 2>&1 || exit 1
+step prof_d4; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d4 -- python bench.py --steps 40 --warmup 4 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --min-seconds 0 > $OUT/prof_d4.log 2>&1 || exit 1
+step prof_d1; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1 -- python bench.py --steps 40 --warmup 4 --depth 1 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --min-seconds 0 > $OUT/prof_d1.log 2>&1 || exit 1
+step prof_open; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_open -- python tools/open_loop.py 20 5 > $OUT/prof_open.log 2>&1 || exit 1
+python tools/trace_timeline.py $(find $OUT/prof_open -name "*kernel_trace.csv" | head -1) > $OUT/open_timeline.txt 2>&1
 step pmc_fetch; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_fetch.log 2>&1 || exit 1
 step pmc_write; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_write.log 2>&1 || exit 1
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json || exit 1
 export HALO_BENCH_BACKEND=gloo
 for N in 2 4; do
-  step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 > $OUT/bench_gloo$N.json 2> $OUT/bench_gloo$N.err || exit 1
+  step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 2> $OUT/bench_gloo$N.err | grep '^{' > $OUT/bench_gloo$N.json || exit 1
 done
-step gloo2_index; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 64 --warmup 8 --shard index > $OUT/bench_gloo2_index.json 2> $OUT/bench_gloo2_index.err || exit 1
+step gloo2_index; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 64 --warmup 8 --shard index 2> $OUT/bench_gloo2_index.err | grep '^{' > $OUT/bench_gloo2_index.json || exit 1
+# BASELINE config 5 shape: n = 2^24 in index shards (two ranks sharing this GPU: 2^23 points each)
+step gloo2_index_2_24; timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 2 --log-n 24 --steps 12 --warmup 2 --shard index --min-seconds 0 2> $OUT/bench_gloo2_index_2_24.err | grep '^{' > $OUT/bench_gloo2_index_2_24.json || exit 1
 unset HALO_BENCH_BACKEND
 step asdl64;  timeout -k 10 600 python tools/time_acc.py 20 64 > $OUT/asdl64.json 2> $OUT/asdl64.err || exit 1
 # keep only the summaries (traces are large)
