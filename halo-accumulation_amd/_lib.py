@@ -26,7 +26,7 @@ class HaloReject(ValueError):
 
 def build(force: bool = False, jobs: int = 4) -> str:
     """Compile every HIP translation unit for gfx950 into libhalo_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".hpp", ".cpp"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     srcs.append(os.path.join(PKG, "..", "include", "halo_accumulation.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:

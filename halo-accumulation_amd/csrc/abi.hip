@@ -178,7 +178,11 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
         st->d_G = priv.d_G; st->d_c = priv.d_c; st->d_z = priv.d_z;
         st->d_s = priv.d_s; st->d_s2 = priv.d_s2; st->d_FL = priv.d_FL; st->d_FR = priv.d_FR;
         st->d_pbar = st->borrowed ? priv.d_pbar : nullptr;
-        if (hipMemcpyAsync(st->d_G, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        // The key is only copied when it is going to be folded in place round by round; the no-fold forms read the
+        // context's own bases until the first real fold writes d_G (and may then use the context's fixed-base table).
+        bool read_only_key = defer || n <= kNoFoldSize;
+        st->G_src = read_only_key ? ctx->d_bases : st->d_G;
+        if ((!read_only_key && hipMemcpyAsync(st->d_G, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ||
             hipMemcpyAsync(st->d_c, d_coeffs_padded, n * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             set_error("ipa_begin: copy failed"); rc = HALO_E_DEVICE; break;
         }
@@ -595,9 +599,9 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         if (rc) return rc;
         HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
         HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
-        rc = msm_enqueue(ctx, 0, st->d_G, st->d_FL, true, st->M);
+        rc = msm_enqueue(ctx, 0, st->G_src, st->d_FL, true, st->M);
         if (rc) return rc;
-        rc = msm_enqueue(ctx, 1, st->d_G, st->d_FR, true, st->M);
+        rc = msm_enqueue(ctx, 1, st->G_src, st->d_FR, true, st->M);
     } else {
         rc = msm_enqueue(ctx, 0, st->d_G, st->d_c + 4 * m, true, m);
         if (rc) return rc;
@@ -609,14 +613,8 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     ctx->stream = ctx->streams[2];
     int rcd = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
     ctx->stream = saved;
-    rc = msm_wait(ctx, 0, 1);
-    int rc2 = msm_wait(ctx, 1, 1);
-    if (rc || rc2 || rcd) {
-        if (!rc2 && rc) { /* slot 1 was waited for: nothing left in flight */ }
-        return rc ? rc : (rc2 ? rc2 : rcd);
-    }
-    // Window combine (~250 doublings each), the H' term and the normalisation of R on the helper thread while this
-    // thread does L's: pure host arithmetic on both sides.
+    // Window combine (~250 doublings), the H' term and the normalisation of L start on the helper thread as soon as L's
+    // launches are done, while this thread still waits for R's and then does R's: pure host arithmetic on both sides.
     auto finish_one = [st, ctx, with_hterm](int slot, const host::Fr &dot, host::Point *out) {
         host::Point p;
         msm_combine(ctx, slot, &p, 1);
@@ -627,9 +625,13 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         *out = p;
     };
     host::Fr dl = dots[0], dr = dots[1];
-    ctx->worker.submit([&finish_one, &Rp, dr] { finish_one(1, dr, &Rp); });
-    finish_one(0, dl, &Lp);
-    ctx->worker.wait();
+    rc = msm_wait(ctx, 0, 1);
+    bool l_started = !rc && !rcd;
+    if (l_started) ctx->worker.submit([&finish_one, &Lp, dl] { finish_one(0, dl, &Lp); });
+    int rc2 = msm_wait(ctx, 1, 1);
+    if (!rc && !rc2 && !rcd) finish_one(1, dr, &Rp);
+    if (l_started) ctx->worker.wait();
+    if (rc || rc2 || rcd) return rc ? rc : (rc2 ? rc2 : rcd);
     *Lp_out = Lp;
     *Rp_out = Rp;
     return HALO_OK;
@@ -659,8 +661,9 @@ int halo_ipa_round_fold(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_in
     st->m = m;
     if (st->nofold && st->deferred && st->s_len == 4) {
         // two rounds are due: G[j] <- G[j] + s1 G[j+m] + s2 G[j+2m] + s3 G[j+3m] with one shared doubling chain
-        rc = ipa_fold_points4(ctx, st->d_G, m, &st->s_host[1]);
+        rc = ipa_fold_points4(ctx, st->G_src, st->d_G, m, &st->s_host[1]);
         if (rc) return rc;
+        st->G_src = st->d_G;
         st->deferred = m > kNoFoldSize;  // below the switch size the key stays as it is for the remaining rounds
         st->s_host.assign(1, host::Fr::one());
         if (m > 1) return ipa_enter_nofold(st);
@@ -682,7 +685,7 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     if (st->nofold && st->M > 1) {
         // U = G_final[0] = sum_t s[t] * G0[t]
         host::Point Up;
-        rc = msm_run(ctx, st->d_G, st->d_s, true, st->M, &Up);
+        rc = msm_run(ctx, st->G_src, st->d_s, true, st->M, &Up);
         if (!rc) rc = download(ctx, c, st->d_c, 4);
         if (rc) return rc;
         if (ctx->prof.on) ctx->prof.collect();
@@ -690,7 +693,7 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
         return HALO_OK;
     }
     uint64_t g[8];
-    rc = aff_native_to_words(ctx, st->d_G, 1, ctx->d_tmp_a);
+    rc = aff_native_to_words(ctx, st->G_src, 1, ctx->d_tmp_a);
     if (!rc) rc = download(ctx, g, ctx->d_tmp_a, 8);
     if (!rc) rc = download(ctx, c, st->d_c, 4);
     if (rc) return rc;
@@ -717,7 +720,7 @@ int halo_ipa_hiding_partial(halo_ipa *st, uint64_t rng_state, size_t deg, const 
     if (rc) return rc;
     st->pbar_valid = true;
     host::Point part;
-    rc = msm_run(ctx, st->d_G, st->d_pbar, true, st->n, &part);
+    rc = msm_run(ctx, st->G_src, st->d_pbar, true, st->n, &part);
     if (rc) return rc;
     part.store_normalized(Cbar_part);
     return HALO_OK;

@@ -1,5 +1,5 @@
 // Pallas group law on gfx950 (y^2 = x^3 + 5 over Fq, prime order, cofactor 1; group.rs:7-8)
-// over the lazy radix-2^29 field of fq29.cuh.  The integer template argument of Fq<K> is the
+// over the lazy radix-2^29 field of fq29.hpp.  The integer template argument of Fq<K> is the
 // proven bound "value < K*p"; the invariants of the point types below are what makes every
 // product satisfy Ka*Kb <= 120 (checked at compile time):
 //
@@ -16,7 +16,7 @@
 // pairs, zero scalars).  The P = +-Q tests are exact: k*p = k (mod 2^29), so a cheap test on
 // limb 0 filters all but ~K/2^29 of the cases before the full reduction.
 #pragma once
-#include "fq29.cuh"
+#include "fq29.hpp"
 
 namespace halo {
 

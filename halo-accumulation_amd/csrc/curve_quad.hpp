@@ -12,9 +12,9 @@
 // All routines must be called in wave-uniform control flow (DPP reads lanes regardless of their position in
 // the quad, so every lane of a quad has to be executing); per-quad special cases (infinity operands,
 // P + P, P + (-P)) are resolved with selects, and the rare doubling inside an addition is taken by the
-// whole wave when any quad needs it.  Same formulas, same value bounds (Fq<K>) as curve.cuh.
+// whole wave when any quad needs it.  Same formulas, same value bounds (Fq<K>) as curve.hpp.
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace halo {
 

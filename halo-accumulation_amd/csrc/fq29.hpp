@@ -1,7 +1,7 @@
 // Pallas base field Fq for the curve kernels: 9 limbs of 29 bits in 32-bit registers, lazy
 // Montgomery arithmetic with R' = 2^261.
 //
-// Why not the 8 x 32-bit form of field.cuh (kept for Fr and for the C ABI)?  Measured on gfx950
+// Why not the 8 x 32-bit form of field.hpp (kept for Fr and for the C ABI)?  Measured on gfx950
 // (profiles/r01_microbench_instr_throughput.txt): v_mad_u64_u32 issues in ~5.3 cycles per wave,
 // but every carry instruction (v_add_co/v_addc_co, v_lshl_add_u64) costs ~4.6 and the 32-bit-limb
 // product needs one of those per partial product plus register shuffling for the even-aligned
@@ -16,14 +16,14 @@
 // checked by the compiler (static_assert), not by hand.
 //
 // Representation of x in Fq: X = x * 2^261 mod p.  The arkworks/C-ABI form is x * 2^256
-// (field.cuh); fq_from_words / fq_to_words convert with one multiplication each, and the base
+// (field.hpp); fq_from_words / fq_to_words convert with one multiplication each, and the base
 // tables live in HBM in the native form (20 words per affine point) so the conversion is paid
 // once per table, not per use.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "field.cuh"
+#include "field.hpp"
 
 namespace halo {
 

@@ -197,7 +197,7 @@ struct halo_ctx {
     hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
     hipStream_t streams[HALO_SLOTS] = {};
     size_t n = 0;
-    uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.cuh AffN)
+    uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.hpp AffN)
     halo::MsmWorkspace wss[HALO_SLOTS];        // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     int window_bits = 0;
@@ -228,6 +228,8 @@ struct halo_ipa {
     halo_ctx *ctx = nullptr;
     size_t n = 0, m = 0;  // m = current length (n, n/2, ...)
     uint32_t *d_G = nullptr;  // m x 20 words native affine (in-place)
+    const uint32_t *G_src = nullptr;  // where the current key is read from: the context's own table of bases until the first real
+                                      // fold (no copy, and its MSMs may use the context's fixed-base table), d_G afterwards
     uint64_t *d_c = nullptr;  // m x 4
     uint64_t *d_z = nullptr;  // m x 4
     halo::host::FixedBaseTable hp_table;  // window table of the H' this open uses (pcdl.rs:181)
@@ -279,7 +281,7 @@ int smsm_prepare();
 
 // ---- ipa.hip
 int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_mont);
-int ipa_fold_points4(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr s[3]);
+int ipa_fold_points4(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]);
 int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv);
 // out[0] = <xs0, ys0>, out[1] = <xs1, ys1> (either pair may be null to skip)
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,

@@ -5,7 +5,7 @@
 // (coalesced 2 KiB per wave-instruction pair); these kernels are the HBM-bound part of the path.
 // The point fold uses ONE scalar for the whole launch, so every lane runs the same
 // double-and-add schedule with no divergence.
-#include "curve.cuh"
+#include "curve.hpp"
 #include "internal.hpp"
 
 namespace halo {
@@ -112,7 +112,7 @@ struct GlvArg3 {
     uint32_t dig[3][14];  // as GlvArg, one digit string per scalar
     int ndigits;          // longest of the three
 };
-HALO_DEV JacN fold_one4(const uint32_t *__restrict__ G, uint32_t j, uint32_t m, const GlvArg3 &a) {
+HALO_DEV JacN fold_one4(const uint32_t *G, uint32_t j, uint32_t m, const GlvArg3 &a) {
     constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
     constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
     AffN p1 = aff_load(G + AFF_STRIDE * (size_t)(j + m)), p2 = aff_load(G + AFF_STRIDE * (size_t)(j + 2 * m)),
@@ -149,7 +149,8 @@ HALO_DEV JacN fold_one4(const uint32_t *__restrict__ G, uint32_t j, uint32_t m, 
     }
     return jac_madd(acc, aff_load(G + AFF_STRIDE * (size_t)j));
 }
-__global__ __launch_bounds__(256, 2) void k_fold_points4(uint32_t *__restrict__ G, uint32_t m, uint32_t half, GlvArg3 a) {
+// G (read) and out (written) may be the same array: a lane reads the indices j + t m and writes index j only
+__global__ __launch_bounds__(256, 2) void k_fold_points4(const uint32_t *G, uint32_t *out, uint32_t m, uint32_t half, GlvArg3 a) {
     // the first result waits in LDS while the second ladder runs (three bases + the accumulator + a mixed addition's
     // temporaries fill the 256 registers that two waves per SIMD allow); word k of thread t at park[256 k + t]
     __shared__ uint32_t park[27 * 256];
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void k_fold_points4(uint32_t *__restrict__ 
         ob.x = fq_mul(rb.x, z2);
         ob.y = fq_mul(rb.y, fq_mul(z2, zib));
     }
-    aff_store(G + AFF_STRIDE * (size_t)j, oa);
-    if (two) aff_store(G + AFF_STRIDE * (size_t)(j + half), ob);
+    aff_store(out + AFF_STRIDE * (size_t)j, oa);
+    if (two) aff_store(out + AFF_STRIDE * (size_t)(j + half), ob);
 }
 
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
@@ -508,8 +509,8 @@ int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_m
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }
-// G[j] <- G[j] + s[0] G[j+m] + s[1] G[j+2m] + s[2] G[j+3m], j < m
-int ipa_fold_points4(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr s[3]) {
+// dst[j] <- src[j] + s[0] src[j+m] + s[1] src[j+2m] + s[2] src[j+3m], j < m (dst may be src)
+int ipa_fold_points4(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]) {
     if (m == 0) return HALO_OK;
     GlvArg3 a;
     a.ndigits = 0;
@@ -520,7 +521,7 @@ int ipa_fold_points4(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr s[3]
         if (dg.n > a.ndigits) a.ndigits = dg.n;
     }
     size_t half = m >= ((size_t)1 << 17) ? (m + 1) / 2 : m;
-    HALO_LAUNCH(ctx, "k_fold_points4", k_fold_points4, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, d_G, (uint32_t)m, (uint32_t)half, a);
+    HALO_LAUNCH(ctx, "k_fold_points4", k_fold_points4, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, d_src, d_dst, (uint32_t)m, (uint32_t)half, a);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

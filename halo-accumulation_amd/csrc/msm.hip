@@ -22,7 +22,7 @@
 #include <cstring>
 #include <thread>
 
-#include "curve_quad.cuh"
+#include "curve_quad.hpp"
 #include "internal.hpp"
 
 namespace halo {
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, c
     }
 }
 
-// the quad-parallel forms of curve_quad.cuh, one point per 4 lanes: op 4 = a + b (XYZZ add), op 5 = 2a, op 6 = a + b where
+// the quad-parallel forms of curve_quad.hpp, one point per 4 lanes: op 4 = a + b (XYZZ add), op 5 = 2a, op 6 = a + b where
 // every fourth pair is replaced by (a, a) so that general additions and doublings share a wave
 __global__ __launch_bounds__(256) void k_test_point_quad(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -1124,22 +1124,24 @@ int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n,
         work(0, per < n ? per : n);
         for (auto &t : th) t.join();
     }
-    uint64_t *d_tbl = nullptr, *d_canon = nullptr;
-    uint32_t *d_tbl_native = nullptr;
-    HALO_HIP(hipMalloc(&d_tbl, tbl.size() * 8));
-    HALO_HIP(hipMalloc(&d_tbl_native, (size_t)1024 * AFF_STRIDE * 4));
-    HALO_HIP(hipMalloc(&d_canon, canon.size() * 8));
-    HALO_HIP(hipMemcpyAsync(d_tbl, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HALO_HIP(hipMemcpyAsync(d_canon, canon.data(), canon.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = aff_words_to_native(ctx, d_tbl, 1024, d_tbl_native);
-    if (rc) return rc;
+    // three temporaries; freed on every path out of this function
+    struct Tmp {
+        uint64_t *d_tbl = nullptr, *d_canon = nullptr;
+        uint32_t *d_tbl_native = nullptr;
+        ~Tmp() { (void)hipFree(d_tbl); (void)hipFree(d_tbl_native); (void)hipFree(d_canon); }
+    } t;
+    HALO_HIP(hipMalloc(&t.d_tbl, tbl.size() * 8));
+    HALO_HIP(hipMalloc(&t.d_tbl_native, (size_t)1024 * AFF_STRIDE * 4));
+    HALO_HIP(hipMalloc(&t.d_canon, canon.size() * 8));
+    HALO_HIP(hipMemcpyAsync(t.d_tbl, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipMemcpyAsync(t.d_canon, canon.data(), canon.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = aff_words_to_native(ctx, t.d_tbl, 1024, t.d_tbl_native);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, d_tbl_native, reinterpret_cast<const uint32_t *>(d_canon), (uint32_t)n, d_out);
-    HALO_HIP(hipGetLastError());
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_tbl);
-    (void)hipFree(d_tbl_native);
-    (void)hipFree(d_canon);
+    HALO_LAUNCH(ctx, "k_urs", k_urs, grid, block, 0, t.d_tbl_native, reinterpret_cast<const uint32_t *>(t.d_canon), (uint32_t)n, d_out);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);  // the temporaries are in use until here
+    if (e1 != hipSuccess) return hip_fail(e1, "k_urs launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return HALO_OK;
 }
 
@@ -1161,7 +1163,13 @@ static void workspace_release(MsmWorkspace &ws) {
     if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
     ws = MsmWorkspace();
 }
+static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need);
 static int workspace_alloc(MsmWorkspace &ws, const WorkspaceNeed &need) {
+    int rc = workspace_alloc_buffers(ws, need);
+    if (rc) workspace_release(ws);  // a failed allocation part-way leaves nothing behind
+    return rc;
+}
+static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) {
     ws.cap_n = need.n;
     ws.cap_counts = need.counts;
     ws.cap_sorted = need.sorted;

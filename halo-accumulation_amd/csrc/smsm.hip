@@ -8,13 +8,13 @@
 //                       LDS (<= 2^14 counters), point references grouped by bucket, buckets cut into tasks of
 //                       <= kmax entries (balanced), task ids reserved with one atomic per window
 //   k_smsm_accumulate   one lane per task: XYZZ mixed additions (the same inner loop as k_msm_accumulate)
-//   k_smsm_reduce       sum_k k * B_k per window with QUAD-PARALLEL point additions (curve_quad.cuh): a block of
+//   k_smsm_reduce       sum_k k * B_k per window with QUAD-PARALLEL point additions (curve_quad.hpp): a block of
 //                       64 quads reduces 64 * L buckets (running sums per quad, suffix scan and tree over the
 //                       quads through LDS); the last block of a window to finish combines the window's segments
 //                       (ticket counter + __threadfence) and writes the window sum.
 // Results are bit-identical to the general pipeline (same digits, same group law; addition order differs, the
 // normalised result does not).
-#include "curve_quad.cuh"
+#include "curve_quad.hpp"
 #include "internal.hpp"
 
 namespace halo {

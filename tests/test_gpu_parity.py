@@ -86,7 +86,7 @@ def test_field_ops(ctx16k):
 
 
 def test_native_radix29_field(ctx16k):
-    """The lazy 9 x 29-bit Fq of fq29.cuh against big-int arithmetic, through arkworks-form I/O."""
+    """The lazy 9 x 29-bit Fq of fq29.hpp against big-int arithmetic, through arkworks-form I/O."""
     n = 4096
     a, s = orc.rng_scalars(3, n)
     b, _ = orc.rng_scalars(s, n)
@@ -161,7 +161,7 @@ def test_point_ops(ctx16k, urs4096):
 
 
 def test_quad_parallel_point_ops(ctx16k, urs4096):
-    """curve_quad.cuh: one XYZZ addition / doubling shared by the 4 lanes of a quad (DPP broadcasts), against the oracle.
+    """curve_quad.hpp: one XYZZ addition / doubling shared by the 4 lanes of a quad (DPP broadcasts), against the oracle.
     op 4 = a + b, op 5 = 2a, op 6 = a + b with every fourth pair replaced by (a, a), so that general additions and the
     wave-wide doubling branch mix inside one wave; un-normalised inputs, infinity on either side, P + (-P)."""
     n = 300

@@ -1,5 +1,5 @@
 // development aid: quad-parallel XYZZ ops against the lane-serial ones, on the device
-#include "../halo-accumulation_amd/csrc/curve_quad.cuh"
+#include "../halo-accumulation_amd/csrc/curve_quad.hpp"
 #include <cstdio>
 using namespace halo;
 __device__ bool same(const XyzzN &a, const XyzzN &b) {
