@@ -615,21 +615,21 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     ctx->stream = saved;
     // Window combine (~250 doublings), the H' term and the normalisation of L start on the helper thread as soon as L's
     // launches are done, while this thread still waits for R's and then does R's: pure host arithmetic on both sides.
-    auto finish_one = [st, ctx, with_hterm](int slot, const host::Fr &dot, host::Point *out) {
+    // the H' terms only need the dot products: computed now, while the MSMs are still running
+    host::Point hterm[2] = {host::Point::infinity(), host::Point::infinity()};
+    if (with_hterm && !rcd)
+        for (int k = 0; k < 2; ++k) hterm[k] = st->hp_from_scalar ? public_h_table().mul(dots[k] * st->hp_scalar) : st->hp_table.mul(dots[k]);
+    auto finish_one = [ctx, with_hterm, &hterm](int slot, host::Point *out) {
         host::Point p;
         msm_combine(ctx, slot, &p, 1);
-        if (with_hterm) {
-            p = p + (st->hp_from_scalar ? public_h_table().mul(dot * st->hp_scalar) : st->hp_table.mul(dot));
-            p = p.normalized();
-        }
+        if (with_hterm) p = (p + hterm[slot]).normalized();
         *out = p;
     };
-    host::Fr dl = dots[0], dr = dots[1];
     rc = msm_wait(ctx, 0, 1);
     bool l_started = !rc && !rcd;
-    if (l_started) ctx->worker.submit([&finish_one, &Lp, dl] { finish_one(0, dl, &Lp); });
+    if (l_started) ctx->worker.submit([&finish_one, &Lp] { finish_one(0, &Lp); });
     int rc2 = msm_wait(ctx, 1, 1);
-    if (!rc && !rc2 && !rcd) finish_one(1, dr, &Rp);
+    if (!rc && !rc2 && !rcd) finish_one(1, &Rp);
     if (l_started) ctx->worker.wait();
     if (rc || rc2 || rcd) return rc ? rc : (rc2 ? rc2 : rcd);
     *Lp_out = Lp;

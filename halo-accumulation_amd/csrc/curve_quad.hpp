@@ -120,6 +120,79 @@ HALO_DEV void xyzz_add_quad(XyzzN &acc, const XyzzN &q, int ql) {
     acc = r;
 }
 
+// ---------------------------------------------------------------- Jacobian ladders over a quad (uniform-scalar folds of small keys)
+HALO_DEV JacN jac_select(bool take_a, const JacN &a, const JacN &b) {
+    JacN r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.v[i] = take_a ? a.x.v[i] : b.x.v[i];
+        r.y.v[i] = take_a ? a.y.v[i] : b.y.v[i];
+        r.z.v[i] = take_a ? a.z.v[i] : b.z.v[i];
+    }
+    return r;
+}
+// dbl-2009-l (a = 0) as jac_dbl: levels {X^2, Y^2, Y Z} -> {B^2, X B, E^2} -> {E (D - X3)}.  Infinity in -> infinity out.
+HALO_DEV JacN jac_dbl_quad(const JacN &p, int ql) {
+    Fq<8> a1 = quad_sel(ql, p.x, p.y, p.y, p.y);
+    Fq<8> b1 = quad_sel(ql, p.x, p.y, fq_widen<8>(p.z), fq_widen<8>(p.z));
+    Fq<2> r1 = fq_mul(a1, b1);
+    Fq<2> A = quad_bcast<0>(r1), B = quad_bcast<1>(r1), YZ = quad_bcast<2>(r1);
+    Fq<6> E = fq_muls<3>(A);
+    Fq<8> a2 = quad_sel(ql, fq_widen<8>(B), p.x, fq_widen<8>(E), fq_widen<8>(E));
+    Fq<6> b2 = quad_sel(ql, fq_widen<6>(B), fq_widen<6>(B), E, E);
+    Fq<2> r2 = fq_mul(a2, b2);
+    Fq<2> C = quad_bcast<0>(r2), F = quad_bcast<2>(r2);
+    Fq<8> D = fq_muls<4>(quad_bcast<1>(r2));
+    Fq<2> x3 = fq_tighten(fq_sub<16>(F, fq_muls<2>(D)));
+    Fq<2> c8 = fq_tighten(fq_muls<8>(C));
+    Fq<2> r3 = fq_mul(E, fq_sub<2>(D, x3));  // every lane computes the same product: no selection needed
+    JacN r;
+    r.x = fq_widen<8>(x3);
+    r.y = fq_widen<8>(fq_sub<2>(r3, c8));
+    r.z = fq_muls<2>(YZ);
+    return r;
+}
+// madd-2007-bl as jac_madd, q = (beta^e x, +-y) given as (x, y, bconst): levels {Z^2, y Z, x beta^e} -> {U2, S2} ->
+// {H^2, r^2, Z H} -> {H I, X1 I} -> {r (V - X3), Y1 J}.  `live` false (q at infinity) leaves p unchanged.
+HALO_DEV JacN jac_madd_quad(const JacN &p, const Fq<2> &qx, const Fq<2> &qy, const Fq<2> &bconst, bool live, int ql) {
+    bool p_inf = jac_is_inf(p);
+    Fq<4> a1 = quad_sel(ql, p.z, fq_widen<4>(qy), fq_widen<4>(qx), fq_widen<4>(qx));
+    Fq<4> b1 = quad_sel(ql, p.z, p.z, fq_widen<4>(bconst), fq_widen<4>(bconst));
+    Fq<2> r1 = fq_mul(a1, b1);
+    Fq<2> Z1Z1 = quad_bcast<0>(r1), YZ = quad_bcast<1>(r1), X2 = quad_bcast<2>(r1);
+    Fq<2> a2 = quad_sel(ql, X2, YZ, X2, YZ);
+    Fq<2> r2 = fq_mul(a2, Z1Z1);
+    Fq<2> U2 = quad_bcast<0>(r2), S2 = quad_bcast<1>(r2);
+    Fq<10> H = fq_sub<8>(U2, p.x), r0 = fq_sub<8>(S2, p.y);
+    bool h_zero = live && !p_inf && fq_is_zero_modp(H);
+    bool r_zero = h_zero && fq_is_zero_modp(r0);
+    Fq<10> a3 = quad_sel(ql, H, r0, fq_widen<10>(p.z), fq_widen<10>(p.z));
+    Fq<10> b3 = quad_sel(ql, H, r0, H, H);
+    Fq<2> r3 = fq_mul(a3, b3);
+    Fq<8> I = fq_muls<4>(quad_bcast<0>(r3));
+    Fq<2> RR = quad_bcast<1>(r3), ZH = quad_bcast<2>(r3);
+    Fq<10> a4 = quad_sel(ql, H, fq_widen<10>(p.x), H, fq_widen<10>(p.x));
+    Fq<2> r4 = fq_mul(a4, I);
+    Fq<2> J = quad_bcast<0>(r4), V = quad_bcast<1>(r4);
+    Fq<2> x3 = fq_tighten(fq_sub_sub2(fq_muls<4>(RR), J, V));
+    Fq<10> a5 = quad_sel(ql, r0, fq_widen<10>(p.y), r0, fq_widen<10>(p.y));
+    Fq<4> b5 = quad_sel(ql, fq_sub<2>(V, x3), fq_widen<4>(J), fq_sub<2>(V, x3), fq_widen<4>(J));
+    Fq<2> r5 = fq_mul(a5, b5);
+    JacN r;
+    r.x = fq_widen<8>(x3);
+    r.y = fq_muls<2>(fq_sub<2>(quad_bcast<0>(r5), quad_bcast<1>(r5)));
+    r.z = fq_muls<2>(ZH);
+    if (__any(r_zero ? 1 : 0)) {  // P + P: only where a folded key repeats a point
+        JacN d = jac_dbl_quad(p, ql);
+        r = jac_select(r_zero, d, r);
+    }
+    r = jac_select(h_zero && !r_zero, jac_inf(), r);  // P + (-P)
+    JacN from_q;                                       // infinity + q
+    from_q.x = fq_widen<8>(X2); from_q.y = fq_widen<8>(qy); from_q.z = fq_widen<4>(fq_one());
+    r = jac_select(p_inf, from_q, r);
+    return jac_select(live, r, p);
+}
+
 // memory: every lane of the quad reads the whole point (same addresses: one transaction); lane ql stores coordinate ql
 HALO_DEV void xyzz_store_quad(uint32_t *o, const XyzzN &p, int ql) {
     Fq<8> c = quad_sel(ql, p.x, p.y, fq_widen<8>(p.zz), fq_widen<8>(p.zzz));

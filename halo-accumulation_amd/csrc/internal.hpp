@@ -208,7 +208,7 @@ struct halo_ctx {
     uint32_t *d_table = nullptr;           // TBL_W x n native affine points: T[w][i] = 2^(20 w) G_i (built on first use)
     int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
-    size_t nofold_size = (size_t)1 << 16;  // key size at which the IPA stops folding G (0/1 = never)
+    size_t nofold_size = (size_t)1 << 14;  // key size at which the IPA stops folding G (0/1 = never)
     bool batch_verify = true;              // succinct checks of >= 64 instances in two device launches (else a host thread pool)
     int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
     // scratch for host-pointer entry points

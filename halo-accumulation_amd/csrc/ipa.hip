@@ -5,7 +5,7 @@
 // (coalesced 2 KiB per wave-instruction pair); these kernels are the HBM-bound part of the path.
 // The point fold uses ONE scalar for the whole launch, so every lane runs the same
 // double-and-add schedule with no divergence.
-#include "curve.hpp"
+#include "curve_quad.hpp"
 #include "internal.hpp"
 
 namespace halo {
@@ -188,6 +188,52 @@ __global__ __launch_bounds__(256, 2) void k_fold_points4(const uint32_t *G, uint
     }
     aff_store(out + AFF_STRIDE * (size_t)j, oa);
     if (two) aff_store(out + AFF_STRIDE * (size_t)(j + half), ob);
+}
+
+// The same two-level fold for SMALL keys (fewer than 2^16 outputs): there the pass is one latency chain (~128 doublings,
+// ~210 additions, one inversion: 1.5 ms whatever m is), so the 4 lanes of a quad share every group operation
+// (curve_quad.hpp: 3 product levels per doubling, 5 per mixed addition instead of 7 and 11 products) -- one output per quad.
+__global__ __launch_bounds__(256, 2) void k_fold_points4_quad(const uint32_t *G, uint32_t *out, uint32_t m, GlvArg3 a) {
+    constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
+    constexpr uint32_t BETA2[9] = {0xcbd58eb, 0x1a2f8f16, 0xd140efa, 0x7bdfb9, 0x1333ecad, 0xa33785b, 0x4eacc49, 0x9617a1e, 0x4ff6c};
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t j = t >> 2;
+    int ql = (int)(t & 3);
+    bool in = j < m;
+    if (!in) j = m - 1;  // whole quads and waves stay busy (DPP); the surplus quads recompute the last output and do not store
+    AffN p1 = aff_load(G + AFF_STRIDE * (size_t)(j + m)), p2 = aff_load(G + AFF_STRIDE * (size_t)(j + 2 * m)),
+         p3 = aff_load(G + AFF_STRIDE * (size_t)(j + 3 * m));
+    bool live1 = !aff_is_inf(p1), live2 = !aff_is_inf(p2), live3 = !aff_is_inf(p3);
+    Fq<2> one = fq_widen<2>(fq_one()), beta = fq_const(BETA), beta2 = fq_const(BETA2);
+    auto step = [&](JacN &acc, const AffN &p, bool live, uint32_t code) {
+        if (!code) return;  // wave-uniform
+        int e = (int)((code - 1) % 3);
+        Fq<2> bc = e == 0 ? one : (e == 1 ? beta : beta2);
+        Fq<2> y = code > 3 ? fq_neg<2>(p.y) : p.y;
+        acc = jac_madd_quad(acc, p.x, y, bc, live, ql);
+    };
+    JacN acc = jac_inf();
+    int top = a.ndigits - 1;
+#pragma unroll 1
+    for (int word = top / 10; word >= 0; word--) {
+        uint32_t w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+        for (int q = 0; q < 14; q++) {
+            w1 = (q == word) ? a.dig[0][q] : w1;
+            w2 = (q == word) ? a.dig[1][q] : w2;
+            w3 = (q == word) ? a.dig[2][q] : w3;
+        }
+#pragma unroll 1
+        for (int k = (word == top / 10) ? (top % 10) : 9; k >= 0; k--) {
+            acc = jac_dbl_quad(acc, ql);
+            step(acc, p1, live1, (w1 >> (3 * k)) & 7u);
+            step(acc, p2, live2, (w2 >> (3 * k)) & 7u);
+            step(acc, p3, live3, (w3 >> (3 * k)) & 7u);
+        }
+    }
+    AffN lo = aff_load(G + AFF_STRIDE * (size_t)j);
+    acc = jac_madd_quad(acc, lo.x, lo.y, one, !aff_is_inf(lo), ql);
+    if (in && ql == 0) aff_store(out + AFF_STRIDE * (size_t)j, jac_to_aff(acc));  // the inversion: one lane of the quad
 }
 
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
@@ -519,6 +565,11 @@ int ipa_fold_points4(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
         for (int i = 0; i < 14; ++i) a.dig[t][i] = 0;
         for (int i = 0; i < dg.n; ++i) a.dig[t][i / 10] |= (uint32_t)dg.d[i] << (3 * (i % 10));
         if (dg.n > a.ndigits) a.ndigits = dg.n;
+    }
+    if (m < ((size_t)1 << 16)) {  // a latency chain at this size: one output per quad (in place is fine: a quad reads j + t m, writes j)
+        HALO_LAUNCH(ctx, "k_fold_points4_quad", k_fold_points4_quad, dim3((unsigned)((4 * m + 255) / 256)), dim3(256), 0, d_src, d_dst, (uint32_t)m, a);
+        HALO_HIP(hipGetLastError());
+        return HALO_OK;
     }
     size_t half = m >= ((size_t)1 << 17) ? (m + 1) / 2 : m;
     HALO_LAUNCH(ctx, "k_fold_points4", k_fold_points4, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, d_src, d_dst, (uint32_t)m, (uint32_t)half, a);

@@ -28,7 +28,7 @@ constexpr uint32_t TASK_IS_WAVE = 0xFFFFFFFFu;
 // More (the top window, whose few real scalar bits put n / 2^bits entries into each bucket; skewed scalars): wave tasks
 // of <= 4096 entries -- 64 lanes run chains of <= 64 and fold them with a shuffle tree -- so that a bucket never leaves
 // more than a handful of partials to the window-sum kernel.
-HALO_DEV uint32_t bucket_tasks(uint32_t c, uint32_t kmax) { return c <= 4 * kmax ? (c + kmax - 1) / kmax : (c + WAVE_TASK - 1) / WAVE_TASK; }
+HALO_DEV uint32_t bucket_tasks(uint32_t c, uint32_t kmax, uint32_t wave_task) { return c <= 4 * kmax ? (c + kmax - 1) / kmax : (c + wave_task - 1) / wave_task; }
 
 
 // ------------------------------------------------------------------------------ sort + tasks
@@ -41,7 +41,7 @@ HALO_DEV uint32_t bucket_tasks(uint32_t c, uint32_t kmax) { return c <= 4 * kmax
 // has 256 - c (W - 1) bits left) and scalars below the group order only reach the first top_rb * R of them, so its R
 // blocks split THAT stretch (top_rb buckets each, the last one takes the rest up to top_span) instead of idling while
 // block 0 sorts the whole window.
-__global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t R, uint32_t kmax,
+__global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t R, uint32_t kmax, uint32_t wave_task,
                                                     uint32_t top_w, uint32_t top_span, uint32_t top_rb,
                                                     uint32_t base_off, uint32_t *__restrict__ sorted, uint32_t *__restrict__ bk_first,
                                                     uint32_t *__restrict__ bk_nt, uint32_t *__restrict__ task_rec, uint32_t *__restrict__ wt,
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__
             uint32_t c = 0;
             for (uint32_t wv = 0; wv < 16; wv++) c += lds[wv * RB + b];
             cnt_sum += c;
-            uint32_t nt = bucket_tasks(c, kmax);
+            uint32_t nt = bucket_tasks(c, kmax, wave_task);
             task_sum += nt;
             if (c > 4 * kmax) wave_sum += nt;
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__
             lds[wv * RB + b] = pos + c;
             c += t;
         }
-        uint32_t nt = bucket_tasks(c, kmax);
+        uint32_t nt = bucket_tasks(c, kmax, wave_task);
         uint32_t g = w * B + lo_b + b;
         bk_first[g] = tfirst;
         bk_nt[g] = nt;
@@ -476,6 +476,9 @@ __global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restric
 int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
                  uint32_t kmax) {
     const uint16_t *d_digits = reinterpret_cast<const uint16_t *>(ws.d_canon);
+    // entries per wave task: 8 per lane where the launch is throughput-bound, 2 per lane for the latency-bound small ones
+    static const int wt_env = getenv("HALO_SMSM_WAVE_TASK") ? atoi(getenv("HALO_SMSM_WAVE_TASK")) : 0;  // development override
+    uint32_t wave_task = wt_env > 0 ? (uint32_t)wt_env : WAVE_TASK;
     // bucket ranges per window: enough blocks that one CU issues at most ~8K LDS atomics per pass
     uint32_t R = 1;
     while (R < 8 && p.B / (2 * R) >= 64 && n / R > 8192) R <<= 1;
@@ -494,12 +497,12 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
             if (top_span - (R - 1) * top_rb > p.B / R) top_rb = (top_span + R - 1) / R;  // the last block's stretch must fit its histogram
         }
     }
-    HALO_LAUNCH(ctx, "k_smsm_sort", k_smsm_sort, dim3(Wt * R), dim3(1024), lds, d_digits, (uint32_t)n, p.B, R, kmax, top_w, top_span, top_rb,
+    HALO_LAUNCH(ctx, "k_smsm_sort", k_smsm_sort, dim3(Wt * R), dim3(1024), lds, d_digits, (uint32_t)n, p.B, R, kmax, wave_task, top_w, top_span, top_rb,
                 base_off, ws.d_sorted, ws.d_starts, ws.d_counts, ws.d_task_g, ws.d_order, ws.d_biglist, ws.d_meta);
     size_t max_tasks = (size_t)Wt * p.B + n * (size_t)Wt / kmax + 1;
     if (max_tasks > ws.cap_tasks || max_tasks > ws.cap_counts) { set_error("msm: small-path tasks exceed the workspace"); return HALO_E_ARG; }
     // wave tasks: one per bucket of more than 4 kmax entries plus one per further WAVE_TASK entries (3 words each in d_order)
-    size_t max_wave = (size_t)Wt * n / (4 * (size_t)kmax) + (size_t)Wt * n / WAVE_TASK + 1;
+    size_t max_wave = (size_t)Wt * n / (4 * (size_t)kmax) + (size_t)Wt * n / wave_task + 1;
     if (3 * max_wave > ws.cap_tasks) { set_error("msm: small-path wave tasks exceed the workspace"); return HALO_E_ARG; }
     unsigned lane_blocks = (unsigned)((max_tasks + 255) / 256), wave_blocks = (unsigned)((max_wave + 3) / 4);
     HALO_LAUNCH(ctx, "k_smsm_accumulate", k_smsm_accumulate, dim3(lane_blocks + wave_blocks), dim3(256), 0, d_bases, ws.d_sorted, ws.d_task_g,

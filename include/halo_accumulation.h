@@ -227,7 +227,7 @@ int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]);
 /* replay cached hipGraphs of the MSM launch sequence when the same shape repeats (default on) */
 int halo_set_graphs(halo_ctx *ctx, int on);  /* also: environment HALO_GRAPHS=0 at context creation; HALO_TRACE=1 logs every launch */
 /* IPA tuning: key size at which halo_ipa_* stops folding G and switches to MSMs over the fixed
- * folded key (default 2^16; 0 or 1 = always fold).  Results are identical either way. */
+ * folded key (default 2^14; 0 or 1 = always fold).  Results are identical either way. */
 int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 /* IPA tuning: 2 (default) folds G every other round, two halvings at once with one shared doubling chain, the rounds in
  * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */

@@ -110,7 +110,7 @@ def test_gpu_fold_vector(vec, gctx, switch):
         L, R = ipa.round_lr(H)
         assert orc.point_canonical(L) == P(f["L"]) and orc.point_canonical(R) == P(f["R"])
     finally:
-        gctx.set_ipa_switch(1 << 16)
+        gctx.set_ipa_switch(1 << 14)
 
 
 @pytest.mark.gpu

@@ -107,7 +107,7 @@ def ipa_mode(request, ctx):
     ctx.set_ipa_switch(request.param[0])
     ctx.set_fold_levels(request.param[1])
     yield request.param
-    ctx.set_ipa_switch(1 << 16)
+    ctx.set_ipa_switch(1 << 14)
     ctx.set_fold_levels(2)
 
 
