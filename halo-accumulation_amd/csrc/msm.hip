@@ -397,6 +397,7 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
 // The sort is the two-level one (coarse: 512 bucket ranges, runs advance sequentially; fine: one block per range, 1024 buckets,
 // staged in LDS); everything after it (tasks, k_msm_accumulate, combine, window sums) is the general pipeline's, which sees
 // 16 "virtual windows" of 2^15 buckets.
+constexpr uint32_t KMAX = 64;  // largest task length of the bucket kernel (plan.kmax <= KMAX)
 constexpr int TBL_C = 20, TBL_W = 13;
 constexpr uint32_t TBL_B = 1u << (TBL_C - 1);         // buckets
 constexpr uint32_t TBL_RANGES = TBL_B >> 10;          // coarse ranges of 1024 buckets
@@ -420,11 +421,11 @@ __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__
 
 // signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
 __global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, uint32_t *__restrict__ digits,
-                                                     uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b) {
+                                                     uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
     if (blockIdx.x == 0) {
         meta[threadIdx.x] = 0;
-        for (int k = 0; k < 4; k++) zero_b[threadIdx.x + 256 * k] = 0;
+        for (int k = 0; k < 4; k++) { zero_b[threadIdx.x + 256 * k] = 0; zero_t[threadIdx.x + 256 * k] = 0; }
     }
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -556,15 +557,25 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
         if (tid < TBL_RANGES) cur[tid] += tcount[tid];
     }
 }
-// fine sort of run r: counts / absolute starts / task counts of its 1024 buckets, entries placed in [lo, hi) of `sorted`
+// Fine sort of run r: counts and absolute starts of its 1024 buckets, entries placed in [lo, hi) of `sorted` -- and the
+// task lists the general pipeline builds with four more kernels (k_scan_blocks/_top, k_msm_task_bins, k_msm_task_order):
+// a bucket of c entries is ceil(c / kmax) tasks with consecutive ids; the block reserves its ids with one atomic
+// (meta[0]), writes toff[g] = first id (absolute: the block offsets of the two-level scan format stay zero) and task_g, and
+// adds its tasks-per-length counts to meta[2 ..]: k_msm_task_order then lays the tasks out by decreasing length over the
+// WHOLE launch (longest first: with a per-block order the last waves of k_msm_accumulate were long ones, +35 % on it).
+// Multi-task buckets are listed for k_msm_combine (meta[1], meta[140]).
+constexpr uint32_t TBL_STAGE = 35840;  // entries staged in LDS: 140 KiB next to 20 KiB of counters
 __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ presort_fine,
                                                          const uint32_t *__restrict__ cstart, uint32_t kmax, uint32_t *__restrict__ counts,
-                                                         uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t hist[1024], scan[1024];
-    uint32_t r = blockIdx.x, lo = cstart[r], hi = cstart[r + 1];
-    hist[threadIdx.x] = 0;
+                                                         uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ toff,
+                                                         uint32_t *__restrict__ task_g, uint32_t *__restrict__ biglist,
+                                                         uint32_t *__restrict__ meta, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t hist[1024], scan[1024], tscan[1024], lbin[KMAX + 8], misc[2];
+    uint32_t r = blockIdx.x, lo = cstart[r], hi = cstart[r + 1], tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid < KMAX + 8) lbin[tid] = 0;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
+    for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
         uint32_t f[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) f[k] = e + k * 1024 < hi ? presort_fine[e + k * 1024] : 0u;
@@ -573,27 +584,44 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
             if (e + k * 1024 < hi) atomicAdd(&hist[f[k]], 1u);
     }
     __syncthreads();
-    uint32_t mine = hist[threadIdx.x];
-    scan[threadIdx.x] = mine;
+    uint32_t mine = hist[tid], nt = (mine + kmax - 1) / kmax;
+    scan[tid] = mine;
+    tscan[tid] = nt;
+    // lengths of this bucket's tasks: kmax for all but the last
+    if (nt) {
+        if (nt > 1) atomicAdd(&lbin[KMAX - kmax], nt - 1);
+        atomicAdd(&lbin[KMAX - (mine - (nt - 1) * kmax)], 1u);
+    }
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t t = threadIdx.x >= o ? scan[threadIdx.x - o] : 0u;
+        uint32_t a = tid >= o ? scan[tid - o] : 0u, b = tid >= o ? tscan[tid - o] : 0u;
         __syncthreads();
-        scan[threadIdx.x] += t;
+        scan[tid] += a;
+        tscan[tid] += b;
         __syncthreads();
     }
+    if (tid == 1023) misc[0] = atomicAdd(&meta[0], tscan[1023]);  // this block's task ids: [base, base + total)
+    if (tid <= KMAX && lbin[tid]) atomicAdd(&meta[2 + tid], lbin[tid]);  // tasks per length, whole launch
+    __syncthreads();
+    uint32_t begin = lo + scan[tid] - mine, tfirst = misc[0] + tscan[tid] - nt;
     {
-        uint32_t begin = lo + scan[threadIdx.x] - mine;
-        uint32_t g = (r << 10) + threadIdx.x;
+        uint32_t g = (r << 10) + tid;
         counts[g] = mine;
-        ntask[g] = (mine + kmax - 1) / kmax;
+        ntask[g] = nt;
         starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
-        hist[threadIdx.x] = begin;
+        toff[g] = tfirst;   // likewise
+        for (uint32_t j = 0; j < nt; j++) {
+            uint32_t len = j + 1 < nt ? kmax : mine - (nt - 1) * kmax;
+            task_g[tfirst + j] = g | ((KMAX - len) << 24);
+        }
+        if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
+        else if (nt > 1) biglist[TBL_B - 1 - atomicAdd(&meta[140], 1u)] = g;
+        hist[tid] = begin;
     }
     __syncthreads();
-    extern __shared__ uint32_t stage[];  // FINE_STAGE entries
-    bool staged = hi - lo <= FINE_STAGE;
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
+    extern __shared__ uint32_t stage[];  // TBL_STAGE entries
+    bool staged = hi - lo <= TBL_STAGE;
+    for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
         uint32_t v[4], f[4], pos[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     }
     if (staged) {
         __syncthreads();
-        for (uint32_t e = lo + threadIdx.x; e < hi; e += 1024) sorted[e] = stage[e - lo];
+        for (uint32_t e = lo + tid; e < hi; e += 1024) sorted[e] = stage[e - lo];
     }
 }
 
@@ -665,7 +693,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *blocksum, uint32_t 
 // with two real bits, put n/4 .. n points into one bucket).  ntask[g] = ceil(count/KMAX);
 // toff = exclusive scan of ntask.  One lane per task; a bucket's value is the partial of its
 // first task once k_msm_combine has folded the partials of multi-task buckets into it.
-constexpr uint32_t KMAX = 64;  // largest task length (plan.kmax <= KMAX)
+// (KMAX, the largest task length, is defined with the table pipeline above)
 
 HALO_DEV uint32_t scan_at(const uint32_t *__restrict__ in_block, const uint32_t *__restrict__ blockoff, uint32_t g) {
     return in_block[g] + blockoff[g >> 12];
@@ -1192,7 +1220,7 @@ static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) 
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
     HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msm_fine_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
-    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tmsm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, FINE_STAGE * 4));
+    HALO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tmsm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, TBL_STAGE * 4));
     { int rc = smsm_prepare(); if (rc) return rc; }
     HALO_HIP(hipMalloc(&ws.d_canon, ws.cap_sorted * 2 + 64));  // u16 digits, n * W of them
     HALO_HIP(hipMalloc(&ws.d_hist, ws.cap_hist * 4));          // [w][chunk][b]
@@ -1410,7 +1438,7 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     uint32_t base_off = (uint32_t)((d_bases - ctx->d_bases) / AFF_STRIDE);
     uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * 13 n bytes <= 2 * 32 n
     HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, mont ? 1 : 0, (uint32_t)n, d_digits,
-                ws.d_meta, ws.d_blockoff);
+                ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
     uint32_t nchunks = 256u / TBL_W;  // 19 chunks per window: about one block per CU
     uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
     chunk_len = (chunk_len + 3) / 4 * 4;
@@ -1423,16 +1451,12 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(TBL_RANGES), 0, rtotal, cstart);
     HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
                 (uint32_t)ctx->n, base_off, ws.d_presort, ws.d_fine16);
-    HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(TBL_RANGES), b1024, FINE_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, ws.d_counts,
-                ws.d_starts, ws.d_ntask, ws.d_sorted);
-    uint32_t total = TBL_B, nblocks = (total + 4095) / 4096;
-    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, total, ws.d_toff, ws.d_tblockoff);
-    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
+    HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(TBL_RANGES), b1024, TBL_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, ws.d_counts,
+                ws.d_starts, ws.d_ntask, ws.d_toff, ws.d_task_g, ws.d_biglist, ws.d_meta, ws.d_sorted);
+    uint32_t total = TBL_B;
     size_t max_tasks = (size_t)total + entries / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
-    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, total, kmax, ws.d_meta,
-                ws.d_task_g, ws.d_biglist);
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
     HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate<true>, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff,
                 ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
