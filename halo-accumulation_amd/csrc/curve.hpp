@@ -61,30 +61,6 @@ HALO_DEV void aff_store(uint32_t *p, const AffN &a) {
     q[3] = make_uint4(a.y.v[2], a.y.v[3], a.y.v[4], a.y.v[5]);
     q[4] = make_uint4(a.y.v[6], a.y.v[7], a.y.v[8], 0u);
 }
-// Packed native affine: the same lazy values (< 2p < 2^256), radix 2^32, x | y = 16 words = 64 bytes: two entries per
-// 128-byte line.  The fixed-base table uses it: its gathers come from HBM (1.7 GB at n = 2^20, far beyond the Infinity
-// Cache), and the 20-word form at a 128-byte stride moves 128 bytes per 80 useful ones.  Unpacking is shifts and masks only.
-constexpr int AFF_PACKED_WORDS = 16;
-HALO_DEV AffN aff_load_packed(const uint32_t *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-    uint32_t wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    AffN r;
-    words_to_limbs(wx, r.x.v);
-    words_to_limbs(wy, r.y.v);
-    return r;
-}
-HALO_DEV void aff_store_packed(uint32_t *p, const AffN &a) {
-    uint32_t wx[8], wy[8];
-    limbs_to_words(a.x.v, wx);
-    limbs_to_words(a.y.v, wy);
-    uint4 *q = reinterpret_cast<uint4 *>(p);
-    q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]);
-    q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
-    q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]);
-    q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
-}
-
 // arkworks affine words (x | y, 8 u64, (0,0) = infinity) <-> native
 HALO_DEV AffN aff_from_words(const uint64_t *w) {
     Fe x = fe_load(w), y = fe_load(w + 4);

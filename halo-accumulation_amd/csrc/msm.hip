@@ -404,19 +404,14 @@ constexpr uint32_t TBL_RANGES = TBL_B >> 10;          // coarse ranges of 1024 b
 constexpr uint32_t TBL_VW = TBL_B >> 15;              // virtual windows of 2^15 buckets for the window-sum kernels
 constexpr uint32_t TDIGIT_NONE = 0xFFFFFFFFu;
 
-// next[i] = 2^c * prev[i] (c = 0: a copy), affine in (the context's 128-byte entries if prev_native, else packed), packed affine
-// out (one Fermat inversion per point and window: paid once per context)
-__global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__ prev, int prev_native, uint32_t n, int c, uint32_t *__restrict__ next) {
+// next[i] = 2^c * prev[i], affine in, affine out (one Fermat inversion per point: paid once per context)
+__global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__ prev, uint32_t n, int c, uint32_t *__restrict__ next) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    AffN a = prev_native ? aff_load(prev + AFF_STRIDE * (size_t)i) : aff_load_packed(prev + AFF_PACKED_WORDS * (size_t)i);
-    if (c > 0) {
-        JacN p = jac_from_aff(a);
+    JacN p = jac_from_aff(aff_load(prev + AFF_STRIDE * (size_t)i));
 #pragma unroll 1
-        for (int k = 0; k < c; k++) p = jac_dbl(p);
-        a = jac_to_aff(p);
-    }
-    aff_store_packed(next + AFF_PACKED_WORDS * (size_t)i, a);
+    for (int k = 0; k < c; k++) p = jac_dbl(p);
+    aff_store(next + AFF_STRIDE * (size_t)i, jac_to_aff(p));
 }
 
 // signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
@@ -770,8 +765,6 @@ __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restri
     if (live) order[base[bin] + rank] = t;
 }
 
-// PACKED: the bases are the fixed-base table's 64-byte entries (aff_load_packed), else a key's 128-byte entries
-template <bool PACKED>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
                                                         const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
@@ -789,17 +782,13 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     XyzzN acc = xyzz_inf();
     // the next point's index and coordinates are fetched before the current mixed add is issued, so the
     // gather latency hides behind ~10k cycles of arithmetic even at two waves per SIMD
-    auto fetch = [&](uint32_t entry) -> AffN {
-        size_t idx = entry & 0x7fffffffu;
-        return PACKED ? aff_load_packed(bases + AFF_PACKED_WORDS * idx) : aff_load(bases + AFF_STRIDE * idx);
-    };
     uint32_t e = sorted[st];
-    AffN nxt = fetch(e);
+    AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
     for (uint32_t k = 0; k < cnt; k++) {
         AffN p = aff_cneg(nxt, (e >> 31) != 0);
         if (k + 1 < cnt) {
             e = sorted[st + k + 1];
-            nxt = fetch(e);
+            nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
         }
         xyzz_madd(acc, p);
     }
@@ -1409,13 +1398,12 @@ static int table_build(halo_ctx *ctx) {
     if (ctx->d_table) return HALO_OK;
     size_t n = ctx->n;
     alloc_epoch_bump(ctx);
-    if (hipMalloc(&ctx->d_table, (size_t)TBL_W * n * AFF_PACKED_WORDS * 4) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
-    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p [%p, +%zu)\n", (void *)ctx, (void *)ctx->d_table, (size_t)TBL_W * n * AFF_PACKED_WORDS * 4);
-    dim3 gridn((unsigned)((n + 255) / 256)), b256(256);
-    HALO_LAUNCH(ctx, "k_table_step", k_table_step, gridn, b256, 0, ctx->d_bases, 1, (uint32_t)n, 0, ctx->d_table);  // window 0: the key itself, packed
+    if (hipMalloc(&ctx->d_table, (size_t)TBL_W * n * 128) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
+    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p [%p, +%zu)\n", (void *)ctx, (void *)ctx->d_table, (size_t)TBL_W * n * 128);
+    HALO_HIP(hipMemcpyAsync(ctx->d_table, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream));
     for (int w = 1; w < TBL_W; ++w)
-        HALO_LAUNCH(ctx, "k_table_step", k_table_step, gridn, b256, 0, ctx->d_table + (size_t)(w - 1) * n * AFF_PACKED_WORDS, 0, (uint32_t)n, TBL_C,
-                    ctx->d_table + (size_t)w * n * AFF_PACKED_WORDS);
+        HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->d_table + (size_t)(w - 1) * n * AFF_STRIDE,
+                    (uint32_t)n, TBL_C, ctx->d_table + (size_t)w * n * AFF_STRIDE);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipStreamSynchronize(ctx->stream));
     return HALO_OK;
@@ -1458,7 +1446,7 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate<true>, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff,
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff,
                 ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 total, 512u, ws.d_buckets);
@@ -1563,7 +1551,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax,
                 ws.d_meta, ws.d_task_g, ws.d_biglist);
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate<false>, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
                 ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 (uint32_t)total, 512u, ws.d_buckets);
