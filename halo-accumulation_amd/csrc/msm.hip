@@ -81,6 +81,7 @@ HALO_DEV Digit next_digit(const uint32_t *words /*9 words in LDS*/, int w, int c
 // Digits are stored once as u16: (|d| - 1) | sign << 15, 0xFFFF for a zero digit (|d| - 1 = 2^15 - 1
 // with the sign set cannot occur: negative digits have magnitude <= B - 1).  Layout [w][i].
 constexpr uint32_t DIGIT_NONE = 0xFFFFu;
+constexpr uint32_t KMAX = 64;  // largest task length of the bucket kernel (plan.kmax <= KMAX)
 
 // Windows [w0, w1) are written (a window shard still walks the carry chain from window 0).
 // Block (0, 0) also clears the launch's small state (meta: 256 words; zero_b: the 1024 block offsets where the sort
@@ -90,12 +91,14 @@ constexpr uint32_t DIGIT_NONE = 0xFFFFu;
 struct MemberScalars { const uint64_t *p[MSM_MAX_BATCH]; };
 __global__ __launch_bounds__(256) void k_msm_recode(MemberScalars scalars, int mont, uint32_t n, int c, int w0, int w1, uint32_t B,
                                                     uint16_t *__restrict__ digits, uint32_t *__restrict__ meta,
-                                                    uint32_t *__restrict__ zero_b) {
+                                                    uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         meta[threadIdx.x] = 0;
         if (zero_b)
             for (int k = 0; k < 4; k++) zero_b[threadIdx.x + 256 * k] = 0;
+        if (zero_t)  // two-level sort: the fine pass writes absolute first-task ids (block offsets stay zero)
+            for (int k = 0; k < 4; k++) zero_t[threadIdx.x + 256 * k] = 0;
     }
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_msm_scatter(const uint16_t *__restrict
 #endif
 constexpr int FINE_BITS = HALO_FINE_BITS;
 constexpr uint32_t NC_MAX = 32768u >> FINE_BITS;  // bucket ranges per window at c = 16
-constexpr uint32_t FINE_STAGE = 37888;             // entries staged in LDS by the fine pass: 148 KiB of the CU's 160 KiB
+constexpr uint32_t FINE_STAGE = 36864;             // entries staged in LDS by the fine pass: 144 KiB of the CU's 160 KiB
 
 // coarse histogram: chist[(w * nchunks + chunk) * NC + c]; one private row of counters per wave
 __global__ __launch_bounds__(1024) void k_msm_coarse_hist(const uint16_t *__restrict__ digits, uint32_t n, uint32_t NC, uint32_t nchunks,
@@ -323,9 +326,14 @@ __global__ __launch_bounds__(1024) void k_msm_coarse_scatter(const uint16_t *__r
 template <bool PACKED>
 __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ digits, uint32_t n,
                                                         uint32_t B, uint32_t NC, const uint32_t *__restrict__ cstart, uint32_t W_member,
-                                                        MemberOffsets offs, uint32_t kmax, uint32_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t hist[1 << FINE_BITS], scan[1 << FINE_BITS];
+                                                        MemberOffsets offs, uint32_t kmax, uint32_t total_buckets, uint32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ toff,
+                                                        uint32_t *__restrict__ task_g, uint32_t *__restrict__ biglist, uint32_t *__restrict__ meta,
+                                                        uint32_t *__restrict__ sorted) {
+    // Besides the sort: the task lists (a bucket of c entries = ceil(c / kmax) tasks with consecutive ids reserved with one
+    // atomic per block, toff = absolute first id, task_g, tasks-per-length counts for k_msm_task_order in meta[2 ..], the
+    // multi-task buckets for k_msm_combine) -- what k_scan_blocks/_top + k_msm_task_bins do for the one-level sort.
+    __shared__ uint32_t hist[1 << FINE_BITS], scan[1 << FINE_BITS], tscan[1 << FINE_BITS], lbin[KMAX + 8], misc[2];
     constexpr uint32_t FMASK = (1u << FINE_BITS) - 1u, IMASK = PACKED ? 0x1FFFFFu : 0x7FFFFFFFu;
     uint32_t p = blockIdx.x, w = p / NC, c = p % NC;
     uint32_t lo = cstart[p], hi = cstart[p + 1];
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
     constexpr uint32_t NB = 1u << FINE_BITS;  // buckets of this block (<= 1024 threads: one bucket per thread at most)
     bool owner = threadIdx.x < NB;
     if (owner) hist[threadIdx.x] = 0;
+    if (threadIdx.x < KMAX + 8) lbin[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {  // four independent entries per lane per trip
         uint32_t v[4];
@@ -345,21 +354,32 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
             if (e + k * 1024 < hi) atomicAdd(&hist[fine_of(v[k])], 1u);
     }
     __syncthreads();
-    uint32_t mine = owner ? hist[threadIdx.x] : 0u;
-    if (owner) scan[threadIdx.x] = mine;
+    uint32_t mine = owner ? hist[threadIdx.x] : 0u, nt = (mine + kmax - 1) / kmax;
+    if (owner) { scan[threadIdx.x] = mine; tscan[threadIdx.x] = nt; }
+    if (nt) {  // lengths of this bucket's tasks: kmax for all but the last
+        if (nt > 1) atomicAdd(&lbin[KMAX - kmax], nt - 1);
+        atomicAdd(&lbin[KMAX - (mine - (nt - 1) * kmax)], 1u);
+    }
     __syncthreads();
     for (uint32_t o = 1; o < NB; o <<= 1) {
-        uint32_t t = (owner && threadIdx.x >= o) ? scan[threadIdx.x - o] : 0u;
+        uint32_t t = (owner && threadIdx.x >= o) ? scan[threadIdx.x - o] : 0u, t2 = (owner && threadIdx.x >= o) ? tscan[threadIdx.x - o] : 0u;
         __syncthreads();
-        if (owner) scan[threadIdx.x] += t;
+        if (owner) { scan[threadIdx.x] += t; tscan[threadIdx.x] += t2; }
         __syncthreads();
     }
+    if (threadIdx.x == NB - 1) misc[0] = atomicAdd(&meta[0], tscan[NB - 1]);  // this block's task ids: [base, base + total)
+    if (threadIdx.x <= KMAX && lbin[threadIdx.x]) atomicAdd(&meta[2 + threadIdx.x], lbin[threadIdx.x]);
+    __syncthreads();
     if (owner) {
-        uint32_t begin = lo + scan[threadIdx.x] - mine;
+        uint32_t begin = lo + scan[threadIdx.x] - mine, tfirst = misc[0] + tscan[threadIdx.x] - nt;
         uint32_t g = w * B + (c << FINE_BITS) + threadIdx.x;
         counts[g] = mine;
-        ntask[g] = (mine + kmax - 1) / kmax;
-        starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the launcher
+        ntask[g] = nt;
+        starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
+        toff[g] = tfirst;   // likewise
+        for (uint32_t j = 0; j < nt; j++) task_g[tfirst + j] = g | ((KMAX - (j + 1 < nt ? kmax : mine - (nt - 1) * kmax)) << 24);
+        if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
+        else if (nt > 1) biglist[total_buckets - 1 - atomicAdd(&meta[140], 1u)] = g;
         hist[threadIdx.x] = begin;  // now the bucket's write cursor
     }
     __syncthreads();
@@ -397,7 +417,6 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
 // The sort is the two-level one (coarse: 512 bucket ranges, runs advance sequentially; fine: one block per range, 1024 buckets,
 // staged in LDS); everything after it (tasks, k_msm_accumulate, combine, window sums) is the general pipeline's, which sees
 // 16 "virtual windows" of 2^15 buckets.
-constexpr uint32_t KMAX = 64;  // largest task length of the bucket kernel (plan.kmax <= KMAX)
 constexpr int TBL_C = 20, TBL_W = 13;
 constexpr uint32_t TBL_B = 1u << (TBL_C - 1);         // buckets
 constexpr uint32_t TBL_RANGES = TBL_B >> 10;          // coarse ranges of 1024 buckets
@@ -1493,7 +1512,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         srcs.p[b] = members.scalars[b];
     }
     HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, dim3(gridn.x, (unsigned)p.batch), b256, 0, srcs, mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
-                d_digits, ws.d_meta, ws.d_blockoff);
+                d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
     // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
     uint32_t kmax = msm_kmax(ctx, n);
     if (ctx->small_path != 0 && n <= ((size_t)1 << 16) && p.batch == 1 && p.B <= 16384 &&
@@ -1530,10 +1549,10 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
                     packed, ws.d_presort);
         if (packed)
             HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<true>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
-                        offs, kmax, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_sorted);
+                        offs, kmax, (uint32_t)total, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_toff, ws.d_task_g, ws.d_biglist, ws.d_meta, ws.d_sorted);
         else
             HALO_LAUNCH(ctx, "k_msm_fine_sort", k_msm_fine_sort<false>, dim3(P), b1024, FINE_STAGE * 4, ws.d_presort, d_digits, (uint32_t)n, p.B, NC, cstart, Wm,
-                        offs, kmax, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_sorted);
+                        offs, kmax, (uint32_t)total, ws.d_counts, ws.d_starts, ws.d_ntask, ws.d_toff, ws.d_task_g, ws.d_biglist, ws.d_meta, ws.d_sorted);
     } else {
         HALO_LAUNCH(ctx, "k_msm_hist", k_msm_hist, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, vec, ws.d_hist);
         HALO_LAUNCH(ctx, "k_msm_colsum", k_msm_colsum, dim3((unsigned)((total + 255) / 256)), b256, 0, ws.d_hist, p.B, nchunks, (uint32_t)total,
@@ -1543,13 +1562,15 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         HALO_LAUNCH(ctx, "k_msm_scatter", k_msm_scatter, gridh, b1024, lds_bytes, d_digits, (uint32_t)n, p.B, nchunks, chunk_len, ws.d_hist,
                     ws.d_starts, ws.d_blockoff, Wm, offs, vec, ws.d_sorted);
     }
-    HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
-    HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
     size_t max_tasks = total + n * (size_t)Wt / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
-    HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax,
-                ws.d_meta, ws.d_task_g, ws.d_biglist);
+    if (!two_level) {  // (the two-level sort's fine pass has already written the task lists)
+        HALO_LAUNCH(ctx, "k_scan_blocks", k_scan_blocks, dim3(nblocks), b256, 0, ws.d_ntask, (uint32_t)total, ws.d_toff, ws.d_tblockoff);
+        HALO_LAUNCH(ctx, "k_scan_top", k_scan_top, dim3(1), dim3(1024), 0, ws.d_tblockoff, nblocks);
+        HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax,
+                    ws.d_meta, ws.d_task_g, ws.d_biglist);
+    }
     HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
     HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
                 ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
