@@ -378,11 +378,23 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
         starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
         toff[g] = tfirst;   // likewise
         for (uint32_t j = 0; j < nt; j++) task_g[tfirst + j] = g | ((KMAX - (j + 1 < nt ? kmax : mine - (nt - 1) * kmax)) << 24);
-        if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
-        else if (nt > 1) biglist[total_buckets - 1 - atomicAdd(&meta[140], 1u)] = g;
         hist[threadIdx.x] = begin;  // now the bucket's write cursor
     }
+    // multi-task buckets for k_msm_combine: counted in LDS, one reservation per block and list
+    uint32_t big_rank = 0, small_rank = 0;
+    if (owner && nt > 8) big_rank = atomicAdd(&lbin[KMAX + 1], 1u);
+    else if (owner && nt > 1) small_rank = atomicAdd(&lbin[KMAX + 2], 1u);
     __syncthreads();
+    if (threadIdx.x == 0) {
+        lbin[KMAX + 3] = lbin[KMAX + 1] ? atomicAdd(&meta[1], lbin[KMAX + 1]) : 0u;
+        lbin[KMAX + 4] = lbin[KMAX + 2] ? atomicAdd(&meta[140], lbin[KMAX + 2]) : 0u;
+    }
+    __syncthreads();
+    {
+        uint32_t g = w * B + (c << FINE_BITS) + threadIdx.x;
+        if (owner && nt > 8) biglist[lbin[KMAX + 3] + big_rank] = g;
+        else if (owner && nt > 1) biglist[total_buckets - 1 - (lbin[KMAX + 4] + small_rank)] = g;
+    }
     extern __shared__ uint32_t stage[];  // FINE_STAGE entries: the block's whole output region when it fits
     bool staged = hi - lo <= FINE_STAGE;
     for (uint32_t e = lo + threadIdx.x; e < hi; e += 4 * 1024) {
@@ -417,9 +429,14 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
 // The sort is the two-level one (coarse: 512 bucket ranges, runs advance sequentially; fine: one block per range, 1024 buckets,
 // staged in LDS); everything after it (tasks, k_msm_accumulate, combine, window sums) is the general pipeline's, which sees
 // 16 "virtual windows" of 2^15 buckets.
-constexpr int TBL_C = 20, TBL_W = 13;
+#ifndef HALO_TBL_C
+#define HALO_TBL_C 20
+#endif
+constexpr int TBL_C = HALO_TBL_C, TBL_W = (256 + TBL_C - 1) / TBL_C;
 constexpr uint32_t TBL_B = 1u << (TBL_C - 1);         // buckets
-constexpr uint32_t TBL_RANGES = TBL_B >> 10;          // coarse ranges of 1024 buckets
+constexpr int TBL_FBITS = TBL_C - 10;                 // fine bits: 512 coarse ranges of 2^TBL_FBITS buckets
+constexpr uint32_t TBL_FMASK = (1u << TBL_FBITS) - 1u;
+constexpr uint32_t TBL_RANGES = TBL_B >> TBL_FBITS;   // coarse ranges
 constexpr uint32_t TBL_VW = TBL_B >> 15;              // virtual windows of 2^15 buckets for the window-sum kernels
 constexpr uint32_t TDIGIT_NONE = 0xFFFFFFFFu;
 
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__res
         uint32_t v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (v[k] != TDIGIT_NONE) atomicAdd(&mine[(v[k] & 0x7FFFFu) >> 10], 1u);
+            if (v[k] != TDIGIT_NONE) atomicAdd(&mine[(v[k] & (TBL_B - 1u)) >> TBL_FBITS], 1u);
     }
     __syncthreads();
     if (threadIdx.x < TBL_RANGES) {
@@ -540,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
             v[4 * h] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & 0x7FFFFu) >> 10], 1u) : 0u;
+        for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & (TBL_B - 1u)) >> TBL_FBITS], 1u) : 0u;
         __syncthreads();
         if (tid < TBL_RANGES) toff[tid] = tcount[tid];
         __syncthreads();
@@ -554,11 +571,11 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (v[k] != TDIGIT_NONE) {
-                uint32_t r = (v[k] & 0x7FFFFu) >> 10;
+                uint32_t r = (v[k] & (TBL_B - 1u)) >> TBL_FBITS;
                 uint32_t slot = toff[r] - tcount[r] + rank[k];
                 uint32_t i = t0 + 4 * tid + (uint32_t)(k >> 2) * 4096 + (uint32_t)(k & 3);
                 t_idx[slot] = (tbase + i) | (v[k] & 0x80000000u);
-                t_fine[slot] = (uint16_t)(v[k] & 0x3FFu);
+                t_fine[slot] = (uint16_t)(v[k] & TBL_FMASK);
                 t_dest[slot] = cur[r] + rank[k];
             }
         __syncthreads();
@@ -598,7 +615,8 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
             if (e + k * 1024 < hi) atomicAdd(&hist[f[k]], 1u);
     }
     __syncthreads();
-    uint32_t mine = hist[tid], nt = (mine + kmax - 1) / kmax;
+    bool owner = tid <= TBL_FMASK;  // one bucket per thread
+    uint32_t mine = owner ? hist[tid] : 0u, nt = (mine + kmax - 1) / kmax;
     scan[tid] = mine;
     tscan[tid] = nt;
     // lengths of this bucket's tasks: kmax for all but the last
@@ -618,8 +636,8 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     if (tid <= KMAX && lbin[tid]) atomicAdd(&meta[2 + tid], lbin[tid]);  // tasks per length, whole launch
     __syncthreads();
     uint32_t begin = lo + scan[tid] - mine, tfirst = misc[0] + tscan[tid] - nt;
-    {
-        uint32_t g = (r << 10) + tid;
+    if (owner) {
+        uint32_t g = (r << TBL_FBITS) + tid;
         counts[g] = mine;
         ntask[g] = nt;
         starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
@@ -628,11 +646,21 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
             uint32_t len = j + 1 < nt ? kmax : mine - (nt - 1) * kmax;
             task_g[tfirst + j] = g | ((KMAX - len) << 24);
         }
-        if (nt > 8) biglist[atomicAdd(&meta[1], 1u)] = g;
-        else if (nt > 1) biglist[TBL_B - 1 - atomicAdd(&meta[140], 1u)] = g;
         hist[tid] = begin;
     }
+    // multi-task buckets for k_msm_combine: counted in LDS, one reservation per block and list (a global atomic per bucket
+    // serialises on one address: 1 ms when a third of the buckets hold more than kmax entries)
+    uint32_t big_rank = 0, small_rank = 0;
+    if (owner && nt > 8) big_rank = atomicAdd(&lbin[KMAX + 1], 1u);
+    else if (owner && nt > 1) small_rank = atomicAdd(&lbin[KMAX + 2], 1u);
     __syncthreads();
+    if (tid == 0) {
+        lbin[KMAX + 3] = lbin[KMAX + 1] ? atomicAdd(&meta[1], lbin[KMAX + 1]) : 0u;
+        lbin[KMAX + 4] = lbin[KMAX + 2] ? atomicAdd(&meta[140], lbin[KMAX + 2]) : 0u;
+    }
+    __syncthreads();
+    if (owner && nt > 8) biglist[lbin[KMAX + 3] + big_rank] = (r << TBL_FBITS) + tid;
+    else if (owner && nt > 1) biglist[TBL_B - 1 - (lbin[KMAX + 4] + small_rank)] = (r << TBL_FBITS) + tid;
     extern __shared__ uint32_t stage[];  // TBL_STAGE entries
     bool staged = hi - lo <= TBL_STAGE;
     for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
