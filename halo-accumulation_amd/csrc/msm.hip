@@ -1276,6 +1276,11 @@ static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) 
     HALO_HIP(hipMalloc(&ws.d_seg, ws.cap_windows * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, ws.cap_windows * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8));
+    if (debug_trace())  // address ranges, so that a faulting address can be mapped to a buffer
+        fprintf(stderr, "[halo] workspace %p: digits=[%p,+%zu) sorted=[%p,+%zu) presort=[%p,+%zu) partials=[%p,+%zu) hist=[%p,+%zu) counts=%p starts=%p ntask=%p toff=%p task_g=%p order=%p seg=%p winsum=%p\n",
+                (void *)&ws, (void *)ws.d_canon, ws.cap_sorted * 2 + 64, (void *)ws.d_sorted, ws.cap_sorted * 4, (void *)ws.d_presort, ws.cap_sorted * 4,
+                (void *)ws.d_buckets, ws.cap_tasks * XYZZ_WORDS * 4, (void *)ws.d_hist, ws.cap_hist * 4, (void *)ws.d_counts, (void *)ws.d_starts,
+                (void *)ws.d_ntask, (void *)ws.d_toff, (void *)ws.d_task_g, (void *)ws.d_order, (void *)ws.d_seg, (void *)ws.d_winsum);
     return HALO_OK;
 }
 // capacity for any single MSM of up to n points, whatever the window size
