@@ -466,6 +466,23 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict_
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
+    if (TBL_C == 20) {
+        // The top window holds 255 - 240 = 15 scalar bits: its 2^20 digits would all land in the lowest 16 of the 512
+        // coarse ranges (3.7 x the entries of the others: their fine-sort blocks ran 110-160 us against 15 us, and the
+        // kernel waited for them).  Every base has order r, so s + k r gives the same point for any k: k = i mod 31
+        // spreads the top digit floor((s + k r) / 2^240) evenly over [0, 31 * 2^14] <= 2^19 at no cost.  Scalars with an
+        // empty top window (zero, short challenges) add nothing to it and stay as they are; so does anything >= 2^254 + 2^240.
+        uint32_t top = my[7] >> 16;
+        uint32_t k = (top != 0 && top <= 16384u) ? i % 31u : 0u;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc += (uint64_t)k * FrCfg::P[j] + my[j];
+            my[j] = (uint32_t)acc;
+            acc >>= 32;
+        }
+        my[8] = (uint32_t)acc;
+    }
     uint32_t carry = 0;
     for (int w = 0; w < TBL_W; w++) {
         Digit d = next_digit(my, w, TBL_C, TBL_B, carry);
@@ -603,18 +620,48 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
                                                          uint32_t *__restrict__ meta, uint32_t *__restrict__ sorted) {
     __shared__ uint32_t hist[1024], scan[1024], tscan[1024], lbin[KMAX + 8], misc[2];
     uint32_t r = blockIdx.x, lo = cstart[r], hi = cstart[r + 1], tid = threadIdx.x;
+#ifdef TMSM_TIMING
+    uint64_t tm[10]; int tmi = 0;
+#define TMARK() do { __syncthreads(); tm[tmi++] = wall_clock64(); } while (0)
+#else
+#define TMARK() do {} while (0)
+#endif
+    TMARK();
     hist[tid] = 0;
     if (tid < KMAX + 8) lbin[tid] = 0;
-    __syncthreads();
-    for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
-        uint32_t f[4];
+    // A run that fits the LDS stage (every run, for uniform scalars) is read ONCE, all loads in flight together, and kept
+    // in registers across the counting and the placement: the kernel is bound by global-load latency (one block of 16
+    // waves per CU), not by LDS or bandwidth.
+    constexpr int PER = TBL_STAGE / 1024;
+    bool staged = hi - lo <= TBL_STAGE;
+    uint32_t rv[PER], rf[PER];
+    if (staged) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) f[k] = e + k * 1024 < hi ? presort_fine[e + k * 1024] : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (e + k * 1024 < hi) atomicAdd(&hist[f[k]], 1u);
+        for (int k = 0; k < PER; k++) {
+            uint32_t e = lo + tid + (uint32_t)k * 1024;
+            bool in = e < hi;
+            rv[k] = in ? presort[e] : 0u;
+            rf[k] = in ? (uint32_t)presort_fine[e] : 0xffffffffu;
+        }
     }
     __syncthreads();
+    TMARK();
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (rf[k] != 0xffffffffu) atomicAdd(&hist[rf[k]], 1u);
+    } else {
+        for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
+            uint32_t f[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[k] = e + k * 1024 < hi ? presort_fine[e + k * 1024] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (e + k * 1024 < hi) atomicAdd(&hist[f[k]], 1u);
+        }
+    }
+    __syncthreads();
+    TMARK();
     bool owner = tid <= TBL_FMASK;  // one bucket per thread
     uint32_t mine = owner ? hist[tid] : 0u, nt = (mine + kmax - 1) / kmax;
     scan[tid] = mine;
@@ -632,9 +679,11 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
         tscan[tid] += b;
         __syncthreads();
     }
+    TMARK();
     if (tid == 1023) misc[0] = atomicAdd(&meta[0], tscan[1023]);  // this block's task ids: [base, base + total)
     if (tid <= KMAX && lbin[tid]) atomicAdd(&meta[2 + tid], lbin[tid]);  // tasks per length, whole launch
     __syncthreads();
+    TMARK();
     uint32_t begin = lo + scan[tid] - mine, tfirst = misc[0] + tscan[tid] - nt;
     if (owner) {
         uint32_t g = (r << TBL_FBITS) + tid;
@@ -650,6 +699,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     }
     // multi-task buckets for k_msm_combine: counted in LDS, one reservation per block and list (a global atomic per bucket
     // serialises on one address: 1 ms when a third of the buckets hold more than kmax entries)
+    TMARK();
     uint32_t big_rank = 0, small_rank = 0;
     if (owner && nt > 8) big_rank = atomicAdd(&lbin[KMAX + 1], 1u);
     else if (owner && nt > 1) small_rank = atomicAdd(&lbin[KMAX + 2], 1u);
@@ -662,8 +712,24 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     if (owner && nt > 8) biglist[lbin[KMAX + 3] + big_rank] = (r << TBL_FBITS) + tid;
     else if (owner && nt > 1) biglist[TBL_B - 1 - (lbin[KMAX + 4] + small_rank)] = (r << TBL_FBITS) + tid;
     extern __shared__ uint32_t stage[];  // TBL_STAGE entries
-    bool staged = hi - lo <= TBL_STAGE;
-    for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {
+    TMARK();
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (rf[k] != 0xffffffffu) stage[atomicAdd(&hist[rf[k]], 1u) - lo] = rv[k];
+        __syncthreads();
+        TMARK();
+        for (uint32_t e = lo + tid; e < hi; e += 1024) sorted[e] = stage[e - lo];
+#ifdef TMSM_TIMING
+        TMARK();
+        if (tid == 0 && (blockIdx.x % 100 == 0 || tm[8] - tm[0] > 3000))
+            printf("fine block %u (%u entries): load %llu hist %llu scan %llu reserve %llu owner %llu biglist %llu place %llu write %llu (x10 ns)\n", blockIdx.x, hi - lo,
+                   (unsigned long long)(tm[1] - tm[0]), (unsigned long long)(tm[2] - tm[1]), (unsigned long long)(tm[3] - tm[2]), (unsigned long long)(tm[4] - tm[3]),
+                   (unsigned long long)(tm[5] - tm[4]), (unsigned long long)(tm[6] - tm[5]), (unsigned long long)(tm[7] - tm[6]), (unsigned long long)(tm[8] - tm[7]));
+#endif
+        return;
+    }
+    for (uint32_t e = lo + tid; e < hi; e += 4 * 1024) {  // an oversized run (skewed scalars): placed directly
         uint32_t v[4], f[4], pos[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -675,15 +741,12 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
         for (int k = 0; k < 4; k++) pos[k] = e + k * 1024 < hi ? atomicAdd(&hist[f[k]], 1u) : 0u;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (e + k * 1024 < hi) {
-                if (staged) stage[pos[k] - lo] = v[k];
-                else sorted[pos[k]] = v[k];
-            }
+            if (e + k * 1024 < hi) sorted[pos[k]] = v[k];
     }
-    if (staged) {
-        __syncthreads();
-        for (uint32_t e = lo + tid; e < hi; e += 1024) sorted[e] = stage[e - lo];
-    }
+#ifdef TMSM_TIMING
+    TMARK();
+    if (tid == 0) printf("fine block %u UNSTAGED (%u entries): total %llu (x10 ns)\n", blockIdx.x, hi - lo, (unsigned long long)(tm[tmi - 1] - tm[0]));
+#endif
 }
 
 // ------------------------------------------------------------------------------ scan
