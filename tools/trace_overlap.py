@@ -24,3 +24,21 @@ tot = 0
 for nm, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     print('  %-24s x%4d avg %8.1f us   per MSM %8.1f us' % (nm, len(v), sum(v) / len(v) / 1e3, sum(v) / K / 1e3)); tot += sum(v)
 print('  sum of kernel time per MSM %.1f us' % (tot / K / 1e3))
+# time with / without an accumulate kernel in flight, and what runs while there is none
+pts = []
+for s, e, nm in sel:
+    pts.append((s, 1, nm)); pts.append((e, -1, nm))
+pts.sort()
+live = collections.Counter(); last = tbeg; with_acc = 0; without = collections.Counter(); n_acc = collections.Counter()
+for t, dv, nm in pts:
+    dt = t - last; last = t
+    if dt > 0:
+        n_acc[live['k_msm_accumulate']] += dt
+        if live['k_msm_accumulate'] > 0: with_acc += dt
+        else: without[tuple(sorted(k for k, v in live.items() if v > 0))] += dt
+    live[nm] += dv
+span = tend - tbeg
+print('  accumulate in flight %.1f%% of the window' % (100 * with_acc / span))
+for k in sorted(n_acc): print('    %d accumulate kernels: %.1f%%' % (k, 100 * n_acc[k] / span))
+for k, v in sorted(without.items(), key=lambda kv: -kv[1])[:10]:
+    print('    no accumulate, running %-60s %.1f%%  (%.1f us per MSM)' % ('+'.join(x.replace('k_msm_', '').replace('k_tmsm_', 't:') for x in k) or 'idle', 100 * v / span, v / K / 1e3))
