@@ -275,6 +275,7 @@ int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const u
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum_plain);
 int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
                  uint32_t kmax);
 int smsm_prepare();

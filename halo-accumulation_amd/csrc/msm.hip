@@ -13,7 +13,8 @@
 //                     buckets cut into tasks of <= kmax entries, tasks sorted by decreasing length
 //   k_msm_accumulate  one lane per task: XYZZ mixed adds over its index list (dominant kernel)
 //   k_msm_combine_*   partials of multi-task buckets folded into the bucket value
-//   k_msm_reduce1/2   sum_k k*B_k per window: lane-local running sums + wave64 shuffle scans
+//   k_msm_reduce1     sum_k k*B_k per segment of a window: lane-local running sums + wave64 shuffle scans
+//   (k_smsm_final)    the segments of a window -> window sum (smsm.hip; quad-parallel, latency-bound)
 //   host              Horner over the W window sums (240 doublings are a 60 us job for one CPU
 //                     core and a > 1 ms serial chain for one GPU lane)
 // msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
@@ -1021,23 +1022,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
         xyzz_store(o + XYZZ_WORDS, tot);
     }
 }
-// one wave per window over its nseg <= 64 segments; segment stride = 64*L buckets = 2^seg_shift
-__global__ __launch_bounds__(64) void k_msm_reduce2(const uint32_t *__restrict__ seg, uint32_t nseg, int seg_shift,
-                                                    uint64_t *__restrict__ winsum, uint64_t *__restrict__ winsum_plain) {
-    __shared__ uint32_t park[36 * 64];
-    uint32_t w = blockIdx.x, lane = threadIdx.x;
-    XyzzN S = xyzz_inf(), T = xyzz_inf();
-    if (lane < nseg) {
-        const uint32_t *o = seg + 2 * XYZZ_WORDS * ((size_t)w * nseg + lane);
-        S = xyzz_load(o);
-        T = xyzz_load(o + XYZZ_WORDS);
-    }
-    wave_weighted_sum(S, T, seg_shift, park, (int)nseg);  // only nseg lanes hold a segment
-    if (lane == 0) {
-        xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
-        if (winsum_plain) xyzz_store_jac_words(winsum_plain + 12 * (size_t)w, S);  // the unweighted sum (table pipeline)
-    }
-}
+// The segments of a window are combined by k_smsm_final (smsm.hip, quad-parallel): see quad_final_enqueue.
 
 // ------------------------------------------------------------------------------ K10 / K11 / format conversion
 // arkworks Jacobian words -> native affine (one Fermat inversion per lane)
@@ -1572,7 +1557,10 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(TBL_VW * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, 32768u, L, logL,
                 nseg, ws.d_seg);
-    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3(TBL_VW), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum, ws.d_winsum + 12 * TBL_VW);
+    {
+        int rc = quad_final_enqueue(ctx, ws, TBL_VW, nseg, logL + 6, ws.d_winsum + 12 * TBL_VW);
+        if (rc) return rc;
+    }
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)2 * TBL_VW * 96, hipMemcpyDeviceToHost, s));
     MsmPlan p;
@@ -1690,7 +1678,10 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(Wt * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
-    HALO_LAUNCH(ctx, "k_msm_reduce2", k_msm_reduce2, dim3((unsigned)Wt), dim3(64), 0, ws.d_seg, nseg, logL + 6, ws.d_winsum, (uint64_t *)nullptr);
+    {
+        int rc = quad_final_enqueue(ctx, ws, (uint32_t)Wt, nseg, logL + 6, nullptr);
+        if (rc) return rc;
+    }
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
     ws.plan = p;

@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256, 2) void k_smsm_reduce(uint32_t *__restrict__ p
 }
 
 // one block per window: the segments' (S, T) -> the window sum
-__global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restrict__ seg, uint32_t nseg, int k, int live_seg, uint64_t *__restrict__ winsum) {
+__global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restrict__ seg, uint32_t nseg, int k, int live_seg, uint64_t *__restrict__ winsum,
+                                                       uint64_t *__restrict__ winsum_plain) {
     __shared__ uint32_t xch[64 * XYZZ_WORDS], parkS[64 * XYZZ_WORDS], parkT[64 * XYZZ_WORDS];
     uint32_t w = blockIdx.x;
     int tid = threadIdx.x, ql = tid & 3, Q = tid >> 2;
@@ -466,7 +467,10 @@ __global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restric
     }
     park_put(parkT, Q, ql, T);
     block_weighted_sum(S, T, k, xch, parkS, parkT, Q, ql, live_seg);
-    if (tid == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
+    if (tid == 0) {
+        xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
+        if (winsum_plain) xyzz_store_jac_words(winsum_plain + 12 * (size_t)w, S);  // the unweighted sum (table pipeline)
+    }
 }
 
 // ------------------------------------------------------------------------------ launch sequence
@@ -525,8 +529,18 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     } else {
         HALO_LAUNCH(ctx, "k_smsm_reduce", k_smsm_reduce<false>, dim3(Wt * nseg), dim3(256), 0, ws.d_buckets, ws.d_starts, ws.d_counts, p.B, L, logL, nseg,
                     live_seg, ws.d_seg, ws.d_meta + 64, ws.d_winsum);
-        HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, logL + 6, live_seg, ws.d_winsum);
+        HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, logL + 6, live_seg, ws.d_winsum, (uint64_t *)nullptr);
     }
+    return HALO_OK;
+}
+
+// The last step of the sorted pipelines of msm.hip as well: the (S, T) records k_msm_reduce1 left per segment (nseg <= 64
+// per window, 2^k buckets each) -> window sums.  A chain of ~20 dependent point operations run by Wt blocks: the quad
+// form takes 80 us where one wave per window took 130.
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum_plain) {
+    int live_seg = 1;
+    while ((uint32_t)live_seg < nseg) live_seg <<= 1;
+    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, k, live_seg, ws.d_winsum, winsum_plain);
     return HALO_OK;
 }
 
