@@ -588,6 +588,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     if (st->m < 2) { set_error("ipa_round_lr: no rounds left"); return HALO_E_ARG; }
     size_t m = st->m / 2;
     int rc;
+    bool batched = false;
     host::Point Lp, Rp;
     // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; the other streams first wait
     // for everything queued on stream 0 (the previous round's folds)
@@ -599,9 +600,22 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         if (rc) return rc;
         HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
         HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
-        rc = msm_enqueue(ctx, 0, st->G_src, st->d_FL, true, st->M);
-        if (rc) return rc;
-        rc = msm_enqueue(ctx, 1, st->G_src, st->d_FR, true, st->M);
+        // Below the fixed-base table's size both MSMs go out as ONE batched launch (same points, two scalar arrays): two
+        // launch sequences on two streams did not overlap -- the second one's 1024-thread sort blocks cannot start on a CU
+        // that still holds waves of the first one's bucket kernel -- so a round took two MSM latencies instead of one.
+        batched = st->M < ((size_t)1 << 20);
+        if (batched) {
+            MsmBatch both;
+            both.count = 2;
+            both.scalars[0] = st->d_FL;
+            both.scalars[1] = st->d_FR;
+            rc = msm_enqueue_batch(ctx, 0, st->G_src, both, true, st->M);
+            if (rc) return rc;
+        } else {
+            rc = msm_enqueue(ctx, 0, st->G_src, st->d_FL, true, st->M);
+            if (rc) return rc;
+            rc = msm_enqueue(ctx, 1, st->G_src, st->d_FR, true, st->M);
+        }
     } else {
         rc = msm_enqueue(ctx, 0, st->d_G, st->d_c + 4 * m, true, m);
         if (rc) return rc;
@@ -619,16 +633,17 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     host::Point hterm[2] = {host::Point::infinity(), host::Point::infinity()};
     if (with_hterm && !rcd)
         for (int k = 0; k < 2; ++k) hterm[k] = st->hp_from_scalar ? public_h_table().mul(dots[k] * st->hp_scalar) : st->hp_table.mul(dots[k]);
-    auto finish_one = [ctx, with_hterm, &hterm](int slot, host::Point *out) {
+    auto finish_one = [ctx, with_hterm, &hterm, batched](int which, host::Point *out) {
         host::Point p;
-        msm_combine(ctx, slot, &p, 1);
-        if (with_hterm) p = (p + hterm[slot]).normalized();
+        if (batched) msm_combine_member(ctx, 0, which, &p);
+        else msm_combine(ctx, which, &p, 1);
+        if (with_hterm) p = (p + hterm[which]).normalized();
         *out = p;
     };
-    rc = msm_wait(ctx, 0, 1);
+    rc = msm_wait(ctx, 0, batched ? 2 : 1);
     bool l_started = !rc && !rcd;
     if (l_started) ctx->worker.submit([&finish_one, &Lp] { finish_one(0, &Lp); });
-    int rc2 = msm_wait(ctx, 1, 1);
+    int rc2 = batched ? HALO_OK : msm_wait(ctx, 1, 1);
     if (!rc && !rc2 && !rcd) finish_one(1, &Rp);
     if (l_started) ctx->worker.wait();
     if (rc || rc2 || rcd) return rc ? rc : (rc2 ? rc2 : rcd);

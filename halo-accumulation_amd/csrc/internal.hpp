@@ -261,6 +261,7 @@ int msm_finish(halo_ctx *ctx, int slot, host::Point *out);
 // may run on another thread); batch as msm_finish_batch
 int msm_wait(halo_ctx *ctx, int slot, int count);
 void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count);
+void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out);
 // the same for `members.count` MSMs of n points each issued as ONE launch sequence; out[count]
 int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const MsmBatch &members, bool scalars_mont, size_t n);
 int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count);

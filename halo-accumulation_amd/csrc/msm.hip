@@ -1599,7 +1599,9 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
                 d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
     // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
     uint32_t kmax = msm_kmax(ctx, n);
-    if (ctx->small_path != 0 && n <= ((size_t)1 << 16) && p.batch == 1 && p.B <= 16384 &&
+    bool same_bases = true;  // the small pipeline takes one base offset: members over the same points (the L and R of an IPA round)
+    for (int b = 1; b < p.batch; ++b) same_bases = same_bases && members.base_off[b] == members.base_off[0];
+    if (ctx->small_path != 0 && n <= ((size_t)1 << 16) && same_bases && p.B <= 16384 &&
         (size_t)Wt * p.B + n * (size_t)Wt / kmax + 1 <= (ws.cap_counts < ws.cap_tasks ? ws.cap_counts : ws.cap_tasks)) {  // smsm.hip: 4-5 launches in all
         int rc = smsm_enqueue(ctx, ws, d_bases, members.base_off[0], n, p, Wt, kmax);
         if (rc) return rc;
@@ -1702,6 +1704,23 @@ int msm_wait(halo_ctx *ctx, int slot, int count) {
     if (ctx->prof.on && !others) ctx->prof.collect();
     return HALO_OK;
 }
+// one member of a batched launch (any thread: reads the slot's pinned window sums only)
+void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out) {
+    const MsmWorkspace &ws = ctx->wss[slot];
+    MsmPlan p = ws.plan;
+    *out = host::Point::infinity();
+    if (p.W == 0) return;
+    int Wm = p.w1 - p.w0;
+    host::Point acc = host::Point::infinity();
+    for (int w = Wm - 1; w >= 0; --w) {
+        if (!acc.is_inf())
+            for (int k = 0; k < p.c; ++k) acc = acc.dbl();
+        acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)b * Wm + w));
+    }
+    if (!acc.is_inf())
+        for (int k = 0; k < p.c * p.w0; ++k) acc = acc.dbl();  // a window shard's weight 2^(c * w0)
+    *out = acc;
+}
 // Horner over the window sums the slot's last launch left in pinned memory (call after msm_wait)
 void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
     const MsmWorkspace &ws = ctx->wss[slot];
@@ -1721,18 +1740,7 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
         out[0] = acc + tot;
         return;
     }
-    int Wm = p.w1 - p.w0;
-    for (int b = 0; b < count; ++b) {
-        host::Point acc = host::Point::infinity();
-        for (int w = Wm - 1; w >= 0; --w) {
-            if (!acc.is_inf())
-                for (int k = 0; k < p.c; ++k) acc = acc.dbl();
-            acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)b * Wm + w));
-        }
-        if (!acc.is_inf())
-            for (int k = 0; k < p.c * p.w0; ++k) acc = acc.dbl();  // a window shard's weight 2^(c * w0)
-        out[b] = acc;
-    }
+    for (int b = 0; b < count; ++b) msm_combine_member(ctx, slot, b, &out[b]);
 }
 int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {
     for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();

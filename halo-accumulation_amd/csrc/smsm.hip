@@ -42,7 +42,7 @@ HALO_DEV uint32_t bucket_tasks(uint32_t c, uint32_t kmax, uint32_t wave_task) { 
 // blocks split THAT stretch (top_rb buckets each, the last one takes the rest up to top_span) instead of idling while
 // block 0 sorts the whole window.
 __global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__ digits, uint32_t n, uint32_t B, uint32_t R, uint32_t kmax, uint32_t wave_task,
-                                                    uint32_t top_w, uint32_t top_span, uint32_t top_rb,
+                                                    uint32_t top_w, uint32_t Wm, uint32_t top_span, uint32_t top_rb,
                                                     uint32_t base_off, uint32_t *__restrict__ sorted, uint32_t *__restrict__ bk_first,
                                                     uint32_t *__restrict__ bk_nt, uint32_t *__restrict__ task_rec, uint32_t *__restrict__ wt,
                                                     uint32_t *__restrict__ order, uint32_t *__restrict__ meta) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void k_smsm_sort(const uint16_t *__restrict__
     uint32_t *hist = lds + (threadIdx.x >> 6) * RB, *sa = lds + 16 * RB, *sb = sa + 1024, *sc = sb + 1024, *misc = sc + 1024, *lbin = misc + 4;  // lbin[0..65): tasks per length, then cursors
     uint32_t w = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x;
     uint32_t lo_b = r * RB, hi_b = lo_b + RB;
-    if (w == top_w) {
+    if (w % Wm == top_w) {  // (a batch lays its members' Wm windows side by side: one top window per member)
         lo_b = r * top_rb;
         hi_b = r == R - 1 ? top_span : lo_b + top_rb;
         if (lo_b > top_span) lo_b = top_span;
@@ -489,7 +489,8 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     while (p.B / R > 2048) R <<= 1;  // 16 private histograms of B / R counters share the CU's LDS
     size_t lds = (16 * ((size_t)p.B / R) + 3072 + 4 + 72) * 4;
     // the top window (present in this launch unless a window shard stops short of it)
-    uint32_t top_w = p.w1 == p.W ? Wt - 1 : 0xFFFFFFFFu, top_span = p.B, top_rb = p.B / R;
+    uint32_t Wm = Wt / (uint32_t)p.batch;  // windows per member
+    uint32_t top_w = p.w1 == p.W ? Wm - 1 : 0xFFFFFFFFu, top_span = p.B, top_rb = p.B / R;
     {
         int top_bits = 256 - p.c * (p.W - 1);  // scalar bits the last window sees (any 256-bit input)
         if (top_bits < p.c) {
@@ -501,7 +502,7 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
             if (top_span - (R - 1) * top_rb > p.B / R) top_rb = (top_span + R - 1) / R;  // the last block's stretch must fit its histogram
         }
     }
-    HALO_LAUNCH(ctx, "k_smsm_sort", k_smsm_sort, dim3(Wt * R), dim3(1024), lds, d_digits, (uint32_t)n, p.B, R, kmax, wave_task, top_w, top_span, top_rb,
+    HALO_LAUNCH(ctx, "k_smsm_sort", k_smsm_sort, dim3(Wt * R), dim3(1024), lds, d_digits, (uint32_t)n, p.B, R, kmax, wave_task, top_w, Wm, top_span, top_rb,
                 base_off, ws.d_sorted, ws.d_starts, ws.d_counts, ws.d_task_g, ws.d_order, ws.d_biglist, ws.d_meta);
     size_t max_tasks = (size_t)Wt * p.B + n * (size_t)Wt / kmax + 1;
     if (max_tasks > ws.cap_tasks || max_tasks > ws.cap_counts) { set_error("msm: small-path tasks exceed the workspace"); return HALO_E_ARG; }
