@@ -64,7 +64,9 @@ void *halo_ctx_stream(halo_ctx *ctx);
 int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
 
 /* ---- group.rs ------------------------------------------------------------------------- */
-/* point_dot_affine (group.rs:24-26): sum_i scalars[i] * GS[off + i], Pippenger in HIP. */
+/* point_dot_affine (group.rs:24-26): sum_i scalars[i] * GS[off + i], Pippenger in HIP.
+ * scalars_are_mont = 1: arkworks' in-memory Fr (Montgomery limbs); 0: plain little-endian integers below 2^255
+ * (canonical Fr values; an unreduced value in [r, 2^255) is taken as it is, which gives the same point). */
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
 /* same, scalars already in device memory (n x 4 limbs, 32-byte aligned device pointer) */
 int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int scalars_are_mont, uint64_t out_jac[12]);

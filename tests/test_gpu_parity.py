@@ -418,6 +418,38 @@ def test_msm_table_pipeline_equals_general(hal):
         c.close()
 
 
+def test_msm_table_top_window_edges(hal):
+    """The table pipeline recodes s + (i mod 31) r when the scalar's top window (bits 240..) is in 1..2^14 -- the same
+    point, since every base has order r.  Scalars around each edge of that rule, given as plain 256-bit integers
+    (scalars_are_mont = 0; values in [r, 2^255) included: the window walk takes them as they are), must give what the general
+    pipeline gives, whose digits are untouched."""
+    import torch
+    n = 1 << 20
+    c = hal.Context(urs_n=n)
+    try:
+        r = pm.R_ORDER
+        edge = [0, 1, (1 << 240) - 1, 1 << 240, (1 << 240) + 1, (16384 << 240) - 1, 16384 << 240, (16384 << 240) + 12345, r - 1, r, r + 1,
+                16385 << 240, (1 << 255) - 19, (1 << 20) - 1, 1 << 19, (1 << 19) + 1, (1 << 239) + (1 << 19)]
+        rng = np.random.default_rng(7)
+        vals = [edge[int(k)] for k in rng.integers(0, len(edge), size=n)]
+        raw = np.zeros((n, 4), dtype=np.uint64)
+        for limb in range(4):
+            raw[:, limb] = np.array([(v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64)
+        d = torch.from_numpy(raw.view(np.int64)).cuda()
+        c.set_table_mode(-1); a = c.msm_dev(d.data_ptr(), n, mont=False)
+        c.set_table_mode(0); b = c.msm_dev(d.data_ptr(), n, mont=False)
+        assert a.tolist() == b.tolist()
+        # and a slice small enough for the oracle: the same values reduced mod r, in Montgomery form
+        m = 1 << 12
+        sc = np.ascontiguousarray(np.stack([orc.fr_to_mont(v % r) for v in vals[:m]]))
+        gs = c.read_bases()[:m]
+        c.set_table_mode(0)
+        small = c.msm_dev(d.data_ptr(), m, mont=False)
+        assert small.tolist() == orc.msm_affine(gs, sc).tolist()
+    finally:
+        c.close()
+
+
 def test_msm_2_20_linearity(ctx1m):
     """Size-independent property: msm(a) + msm(b) == msm(a + b); msm(k a) == k msm(a)."""
     n = 1 << 20
