@@ -68,8 +68,16 @@ struct MsmPlan {
     int batch;    // MSMs sharing the launch sequence (their windows are laid side by side: W * batch in all)
     int w0, w1;   // windows [w0, w1) of 0..W are computed (a window-sharded partial); the result carries 2^(c*w0)
     int table_vw = 0;  // > 0: the fixed-base table pipeline ran; h_winsum holds table_vw weighted sums, then table_vw plain sums
+    int table_vw_bits = 15;  // log2 of the buckets per virtual window
 };
 constexpr int MSM_MAX_BATCH = 8;
+// fixed-base table plan of a context (msm.hip: table_plan)
+struct TblPlan {
+    int c, W, fbits, vw_bits;        // window bits, windows, fine-bucket bits of a coarse range, log2 buckets per virtual window
+    uint32_t B, ranges, vw, spread;  // buckets (2^(c-1)), coarse ranges, virtual windows, modulus of the top-window spread (0: none)
+    int fold_top;                    // scalars >= 2^254 are recoded as r - s with flipped signs (c = 17: the top window is full)
+};
+TblPlan table_plan(size_t key_n);
 // the members of a batched launch: same n, one scalar array and one base offset (in points) each
 struct MsmBatch {
     int count = 1;
@@ -205,7 +213,8 @@ struct halo_ctx {
     int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^17), 0 never, 1 whenever the shape allows
     int task_len = 0;                      // longest chain per lane in k_msm_accumulate (0 = automatic)
     int table_mode = -1;                   // fixed-base tables for MSMs over the context's own bases: -1 automatic (n >= 2^20), 0 never
-    uint32_t *d_table = nullptr;           // TBL_W x n native affine points: T[w][i] = 2^(20 w) G_i (built on first use)
+    uint32_t *d_table = nullptr;           // W x n native affine points: T[w][i] = 2^(c w) G_i (built on first use)
+    halo::TblPlan tbl{};                   // the plan d_table was built for
     int small_path = -1;                   // smsm.hip pipeline: -1 automatic (n <= 2^16, one MSM per launch), 0 never
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 14;  // key size at which the IPA stops folding G (0/1 = never)

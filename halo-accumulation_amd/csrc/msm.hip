@@ -430,16 +430,29 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
 // The sort is the two-level one (coarse: 512 bucket ranges, runs advance sequentially; fine: one block per range, 1024 buckets,
 // staged in LDS); everything after it (tasks, k_msm_accumulate, combine, window sums) is the general pipeline's, which sees
 // 16 "virtual windows" of 2^15 buckets.
-#ifndef HALO_TBL_C
-#define HALO_TBL_C 20
-#endif
-constexpr int TBL_C = HALO_TBL_C, TBL_W = (256 + TBL_C - 1) / TBL_C;
-constexpr uint32_t TBL_B = 1u << (TBL_C - 1);         // buckets
-constexpr int TBL_FBITS = TBL_C - 10;                 // fine bits: 512 coarse ranges of 2^TBL_FBITS buckets
-constexpr uint32_t TBL_FMASK = (1u << TBL_FBITS) - 1u;
-constexpr uint32_t TBL_RANGES = TBL_B >> TBL_FBITS;   // coarse ranges
-constexpr uint32_t TBL_VW = TBL_B >> 15;              // virtual windows of 2^15 buckets for the window-sum kernels
+//
+// Two plans (TblPlan, fixed when a context builds its table):
+//   key of >= 2^20 points: c = 20, 13 windows, 2^19 buckets, 512 coarse ranges of 1024 buckets, 16 virtual windows of 2^15;
+//   key of 2^17 .. 2^19 points (a rank's index shard of a 2^20-point MSM): c = 17, 15 windows (15 x 17 = 255 bits exactly),
+//     2^16 buckets, n / 2048 coarse ranges (so that a range's 15 n / ranges entries fit the fine sort's LDS stage), 16 virtual
+//     windows of 2^12 -- 15 n additions against 16 n, an eighth of the buckets of the general plan's 16 x 2^15.
+constexpr uint32_t TBL_MAX_RANGES = 512;
 constexpr uint32_t TDIGIT_NONE = 0xFFFFFFFFu;
+TblPlan table_plan(size_t key_n) {
+    TblPlan t{};
+    if (key_n >= ((size_t)1 << 20)) {
+        t.c = 20; t.W = 13; t.B = 1u << 19; t.fbits = 10; t.vw_bits = 15; t.spread = 31; t.fold_top = 0;
+    } else {
+        t.c = 17; t.W = 15; t.B = 1u << 16; t.vw_bits = 12; t.spread = 0; t.fold_top = 1;
+        uint32_t ranges = 64;
+        while ((size_t)ranges * 2048 < key_n && ranges < 256) ranges <<= 1;
+        t.fbits = 16;
+        for (uint32_t r = ranges; r > 1; r >>= 1) t.fbits--;
+    }
+    t.ranges = t.B >> t.fbits;
+    t.vw = t.B >> t.vw_bits;
+    return t;
+}
 
 // next[i] = 2^c * prev[i], affine in, affine out (one Fermat inversion per point: paid once per context)
 __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__ prev, uint32_t n, int c, uint32_t *__restrict__ next) {
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__
 }
 
 // signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
-__global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, uint32_t *__restrict__ digits,
+__global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, TblPlan tp, uint32_t *__restrict__ digits,
                                                      uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
     if (blockIdx.x == 0) {
@@ -467,14 +480,34 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict_
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
-    if (TBL_C == 20) {
+    uint32_t flip = 0;
+    if (tp.fold_top && (my[7] >> 30) != 0) {
+        // c = 17: the top window would hold 2^16 (+ carry) = B + 1 for a scalar >= 2^254 -- one value too many.  Such a
+        // scalar is within 2^126 of r: take r - s with every digit's sign flipped (or s - r for an unreduced input).
+        bool ge = true;  // s >= r ?
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            if (my[j] != FrCfg::P[j]) { ge = my[j] > FrCfg::P[j]; break; }
+        }
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t a = ge ? my[j] : FrCfg::P[j], b = ge ? FrCfg::P[j] : my[j];
+            uint64_t d = a - b - borrow;
+            my[j] = (uint32_t)d;
+            borrow = (d >> 32) & 1u;
+        }
+        flip = ge ? 0u : 1u;
+    }
+    if (tp.spread) {
         // The top window holds 255 - 240 = 15 scalar bits: its 2^20 digits would all land in the lowest 16 of the 512
         // coarse ranges (3.7 x the entries of the others: their fine-sort blocks ran 110-160 us against 15 us, and the
         // kernel waited for them).  Every base has order r, so s + k r gives the same point for any k: k = i mod 31
         // spreads the top digit floor((s + k r) / 2^240) evenly over [0, 31 * 2^14] <= 2^19 at no cost.  Scalars with an
         // empty top window (zero, short challenges) add nothing to it and stay as they are; so does anything >= 2^254 + 2^240.
+        // (plan c = 20 only: tp.spread = 31)
         uint32_t top = my[7] >> 16;
-        uint32_t k = (top != 0 && top <= 16384u) ? i % 31u : 0u;
+        uint32_t k = (top != 0 && top <= 16384u) ? i % tp.spread : 0u;
         uint64_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -485,19 +518,19 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict_
         my[8] = (uint32_t)acc;
     }
     uint32_t carry = 0;
-    for (int w = 0; w < TBL_W; w++) {
-        Digit d = next_digit(my, w, TBL_C, TBL_B, carry);
-        digits[(size_t)w * n + i] = d.mag ? ((d.mag - 1) | (d.neg << 31)) : TDIGIT_NONE;
+    for (int w = 0; w < tp.W; w++) {
+        Digit d = next_digit(my, w, tp.c, tp.B, carry);
+        digits[(size_t)w * n + i] = d.mag ? ((d.mag - 1) | ((d.neg ^ flip) << 31)) : TDIGIT_NONE;
     }
 }
 // block (w, chunk): counts of the 512 coarse ranges, one private row per wave
 __global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
-                                                           uint32_t *__restrict__ chist) {
-    __shared__ uint32_t cnt[16 * TBL_RANGES];
+                                                           TblPlan tp, uint32_t *__restrict__ chist) {
+    __shared__ uint32_t cnt[16 * TBL_MAX_RANGES];
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
-    for (uint32_t k = threadIdx.x; k < 16 * TBL_RANGES; k += 1024) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < 16 * TBL_MAX_RANGES; k += 1024) cnt[k] = 0;
     __syncthreads();
-    uint32_t *mine = cnt + TBL_RANGES * (threadIdx.x >> 6);
+    uint32_t *mine = cnt + TBL_MAX_RANGES * (threadIdx.x >> 6);
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint32_t *dg = digits + (size_t)w * n;
     for (uint32_t i = lo + 4 * threadIdx.x; i < hi; i += 4 * 1024) {  // n and chunk_len are multiples of 4
@@ -505,21 +538,21 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__res
         uint32_t v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (v[k] != TDIGIT_NONE) atomicAdd(&mine[(v[k] & (TBL_B - 1u)) >> TBL_FBITS], 1u);
+            if (v[k] != TDIGIT_NONE) atomicAdd(&mine[(v[k] & (tp.B - 1u)) >> tp.fbits], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < TBL_RANGES) {
+    if (threadIdx.x < tp.ranges) {
         uint32_t t = 0;
-        for (int r = 0; r < 16; r++) t += cnt[TBL_RANGES * r + threadIdx.x];
-        chist[(size_t)blockIdx.x * TBL_RANGES + threadIdx.x] = t;
+        for (int r = 0; r < 16; r++) t += cnt[TBL_MAX_RANGES * r + threadIdx.x];
+        chist[(size_t)blockIdx.x * tp.ranges + threadIdx.x] = t;
     }
 }
 // chist[chunk][range] -> exclusive prefix over the chunks of each range (in place); rtotal[range] = the range's size.
 // One block per range: 247 counters, loaded once, scanned in LDS.
-__global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__ chist, uint32_t nchunks_all, uint32_t *__restrict__ rtotal) {
+__global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__ chist, uint32_t nchunks_all, uint32_t ranges, uint32_t *__restrict__ rtotal) {
     __shared__ uint32_t part[256];
     uint32_t r = blockIdx.x, t = threadIdx.x;
-    uint32_t v = t < nchunks_all ? chist[(size_t)t * TBL_RANGES + r] : 0u;  // nchunks_all <= 256
+    uint32_t v = t < nchunks_all ? chist[(size_t)t * ranges + r] : 0u;  // nchunks_all <= 256
     part[t] = v;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -528,23 +561,24 @@ __global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__
         part[t] += o;
         __syncthreads();
     }
-    if (t < nchunks_all) chist[(size_t)t * TBL_RANGES + r] = part[t] - v;
+    if (t < nchunks_all) chist[(size_t)t * ranges + r] = part[t] - v;
     if (t == 255) rtotal[r] = part[255];
 }
 // cstart[r] = start of run r in the presorted array, cstart[512] = number of entries
 __global__ __launch_bounds__(512) void k_tmsm_scan_ranges(const uint32_t *__restrict__ rtotal, uint32_t *__restrict__ cstart) {
-    __shared__ uint32_t part[TBL_RANGES];
+    __shared__ uint32_t part[TBL_MAX_RANGES];
+    const uint32_t ranges = blockDim.x;  // one thread per range
     uint32_t t = threadIdx.x, v = rtotal[t];
     part[t] = v;
     __syncthreads();
-    for (uint32_t off = 1; off < TBL_RANGES; off <<= 1) {
+    for (uint32_t off = 1; off < ranges; off <<= 1) {
         uint32_t o = t >= off ? part[t - off] : 0u;
         __syncthreads();
         part[t] += o;
         __syncthreads();
     }
     cstart[t] = part[t] - v;
-    if (t == TBL_RANGES - 1) cstart[TBL_RANGES] = part[t];
+    if (t == ranges - 1) cstart[ranges] = part[t];
 }
 // Block (w, chunk) appends its entries to the 512 runs: table index | sign << 31, and the bucket's low 10 bits beside it.
 // 247 blocks x 512 runs are too many open cache lines for direct appends (partially filled lines would be evicted and
@@ -553,18 +587,19 @@ __global__ __launch_bounds__(512) void k_tmsm_scan_ranges(const uint32_t *__rest
 constexpr uint32_t TBL_TILE = 8192;
 __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
                                                               const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
-                                                              uint32_t table_n, uint32_t base_off, uint32_t *__restrict__ presort,
+                                                              uint32_t table_n, uint32_t base_off, TblPlan tp, uint32_t *__restrict__ presort,
                                                               uint16_t *__restrict__ presort_fine) {
-    __shared__ uint32_t cur[TBL_RANGES], tcount[TBL_RANGES], toff[TBL_RANGES];
+    __shared__ uint32_t cur[TBL_MAX_RANGES], tcount[TBL_MAX_RANGES], toff[TBL_MAX_RANGES];
+    const uint32_t ranges = tp.ranges, fmask = (1u << tp.fbits) - 1u;
     __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
     __shared__ uint16_t t_fine[TBL_TILE];
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, tid = threadIdx.x;
-    if (tid < TBL_RANGES) cur[tid] = cstart[tid] + chist[(size_t)blockIdx.x * TBL_RANGES + tid];
+    if (tid < ranges) cur[tid] = cstart[tid] + chist[(size_t)blockIdx.x * ranges + tid];
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint32_t *dg = digits + (size_t)w * n;
     uint32_t tbase = w * table_n + base_off;
     for (uint32_t t0 = lo; t0 < hi; t0 += TBL_TILE) {
-        if (tid < TBL_RANGES) tcount[tid] = 0;
+        if (tid < ranges) tcount[tid] = 0;
         __syncthreads();
         // eight digits per thread: two 16-byte loads (n, chunk_len and the tile are multiples of 4)
         uint32_t v[8], rank[8];
@@ -575,25 +610,25 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
             v[4 * h] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & (TBL_B - 1u)) >> TBL_FBITS], 1u) : 0u;
+        for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & (tp.B - 1u)) >> tp.fbits], 1u) : 0u;
         __syncthreads();
-        if (tid < TBL_RANGES) toff[tid] = tcount[tid];
+        if (tid < ranges) toff[tid] = tcount[tid];
         __syncthreads();
-        for (uint32_t off = 1; off < TBL_RANGES; off <<= 1) {  // inclusive scan of the tile's counts (threads 0..511)
-            uint32_t o = (tid < TBL_RANGES && tid >= off) ? toff[tid - off] : 0u;
+        for (uint32_t off = 1; off < ranges; off <<= 1) {  // inclusive scan of the tile's counts (threads 0..511)
+            uint32_t o = (tid < ranges && tid >= off) ? toff[tid - off] : 0u;
             __syncthreads();
-            if (tid < TBL_RANGES) toff[tid] += o;
+            if (tid < ranges) toff[tid] += o;
             __syncthreads();
         }
-        uint32_t total = toff[TBL_RANGES - 1];
+        uint32_t total = toff[ranges - 1];
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (v[k] != TDIGIT_NONE) {
-                uint32_t r = (v[k] & (TBL_B - 1u)) >> TBL_FBITS;
+                uint32_t r = (v[k] & (tp.B - 1u)) >> tp.fbits;
                 uint32_t slot = toff[r] - tcount[r] + rank[k];
                 uint32_t i = t0 + 4 * tid + (uint32_t)(k >> 2) * 4096 + (uint32_t)(k & 3);
                 t_idx[slot] = (tbase + i) | (v[k] & 0x80000000u);
-                t_fine[slot] = (uint16_t)(v[k] & TBL_FMASK);
+                t_fine[slot] = (uint16_t)(v[k] & fmask);
                 t_dest[slot] = cur[r] + rank[k];
             }
         __syncthreads();
@@ -603,7 +638,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
             presort_fine[d] = t_fine[j];
         }
         __syncthreads();
-        if (tid < TBL_RANGES) cur[tid] += tcount[tid];
+        if (tid < ranges) cur[tid] += tcount[tid];
     }
 }
 // Fine sort of run r: counts and absolute starts of its 1024 buckets, entries placed in [lo, hi) of `sorted` -- and the
@@ -615,7 +650,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
 // Multi-task buckets are listed for k_msm_combine (meta[1], meta[140]).
 constexpr uint32_t TBL_STAGE = 35840;  // entries staged in LDS: 140 KiB next to 20 KiB of counters
 __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restrict__ presort, const uint16_t *__restrict__ presort_fine,
-                                                         const uint32_t *__restrict__ cstart, uint32_t kmax, uint32_t *__restrict__ counts,
+                                                         const uint32_t *__restrict__ cstart, uint32_t kmax, TblPlan tp, uint32_t *__restrict__ counts,
                                                          uint32_t *__restrict__ starts, uint32_t *__restrict__ ntask, uint32_t *__restrict__ toff,
                                                          uint32_t *__restrict__ task_g, uint32_t *__restrict__ biglist,
                                                          uint32_t *__restrict__ meta, uint32_t *__restrict__ sorted) {
@@ -663,7 +698,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     }
     __syncthreads();
     TMARK();
-    bool owner = tid <= TBL_FMASK;  // one bucket per thread
+    bool owner = tid < (1u << tp.fbits);  // one bucket per thread
     uint32_t mine = owner ? hist[tid] : 0u, nt = (mine + kmax - 1) / kmax;
     scan[tid] = mine;
     tscan[tid] = nt;
@@ -687,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
     TMARK();
     uint32_t begin = lo + scan[tid] - mine, tfirst = misc[0] + tscan[tid] - nt;
     if (owner) {
-        uint32_t g = (r << TBL_FBITS) + tid;
+        uint32_t g = (r << tp.fbits) + tid;
         counts[g] = mine;
         ntask[g] = nt;
         starts[g] = begin;  // absolute: the block offsets of the two-level scan format are zeroed by the recode kernel
@@ -710,8 +745,8 @@ __global__ __launch_bounds__(1024) void k_tmsm_fine_sort(const uint32_t *__restr
         lbin[KMAX + 4] = lbin[KMAX + 2] ? atomicAdd(&meta[140], lbin[KMAX + 2]) : 0u;
     }
     __syncthreads();
-    if (owner && nt > 8) biglist[lbin[KMAX + 3] + big_rank] = (r << TBL_FBITS) + tid;
-    else if (owner && nt > 1) biglist[TBL_B - 1 - (lbin[KMAX + 4] + small_rank)] = (r << TBL_FBITS) + tid;
+    if (owner && nt > 8) biglist[lbin[KMAX + 3] + big_rank] = (r << tp.fbits) + tid;
+    else if (owner && nt > 1) biglist[tp.B - 1 - (lbin[KMAX + 4] + small_rank)] = (r << tp.fbits) + tid;
     extern __shared__ uint32_t stage[];  // TBL_STAGE entries
     TMARK();
     if (staged) {
@@ -1492,56 +1527,65 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     return HALO_OK;
 }
 
-// T[w][i] = 2^(20 w) G_i over the whole key, built window by window on the context's first table MSM (one-off: 12 passes of
-// 20 doublings and an inversion per point, ~10 ms at n = 2^20)
+// T[w][i] = 2^(c w) G_i over the whole key, built window by window on the context's first table MSM (one-off: W - 1 passes
+// of c doublings and an inversion per point, ~10 ms at n = 2^20)
 static int table_build(halo_ctx *ctx) {
     if (ctx->d_table) return HALO_OK;
     size_t n = ctx->n;
+    TblPlan tp = table_plan(n);
     alloc_epoch_bump(ctx);
-    if (hipMalloc(&ctx->d_table, (size_t)TBL_W * n * 128) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
-    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p [%p, +%zu)\n", (void *)ctx, (void *)ctx->d_table, (size_t)TBL_W * n * 128);
+    if (hipMalloc(&ctx->d_table, (size_t)tp.W * n * 128) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
+    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)ctx->d_table, (size_t)tp.W * n * 128);
     HALO_HIP(hipMemcpyAsync(ctx->d_table, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int w = 1; w < TBL_W; ++w)
+    for (int w = 1; w < tp.W; ++w)
         HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->d_table + (size_t)(w - 1) * n * AFF_STRIDE,
-                    (uint32_t)n, TBL_C, ctx->d_table + (size_t)w * n * AFF_STRIDE);
+                    (uint32_t)n, tp.c, ctx->d_table + (size_t)w * n * AFF_STRIDE);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tbl = tp;
     return HALO_OK;
 }
-// can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key, large enough that
-// 2^19 buckets are well filled, indices within 31 bits.
+// can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key that is at least
+// half of it (the plan's bucket count and coarse ranges are sized for the key), indices within 31 bits.
 static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n) {
     if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.count != 1 || members.parts != 1) return false;
-    if (n < ((size_t)1 << 20) || n % 4 != 0 || (size_t)TBL_W * ctx->n >= ((size_t)1 << 31)) return false;
+    TblPlan tp = table_plan(ctx->n);
+    size_t least = tp.c == 20 ? ((size_t)1 << 20) : ((size_t)1 << 17);
+    if (ctx->n < least || n < least || 2 * n < ctx->n || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
 static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
-    size_t entries = (size_t)TBL_W * n;
-    if (n > ws.cap_n || entries > ws.cap_sorted || TBL_B > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+    const TblPlan tp = ctx->tbl;
+    size_t entries = (size_t)tp.W * n;
+    if (n > ws.cap_n || entries > ws.cap_sorted || tp.B > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
     if (!ws.d_fine16) {
         alloc_epoch_bump(ctx);
         HALO_HIP(hipMalloc(&ws.d_fine16, ws.cap_sorted * 2));
     }
     hipStream_t s = ctx->stream;
     uint32_t base_off = (uint32_t)((d_bases - ctx->d_bases) / AFF_STRIDE);
-    uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * 13 n bytes <= 2 * 32 n
-    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, mont ? 1 : 0, (uint32_t)n, d_digits,
+    uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * W n bytes <= 2 * 32 n
+    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, mont ? 1 : 0, (uint32_t)n, tp, d_digits,
                 ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
-    uint32_t nchunks = 256u / TBL_W;  // 19 chunks per window: about one block per CU
+    uint32_t nchunks = 256u / (uint32_t)tp.W;  // 19 (17) chunks per window: about one block per CU
     uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
     chunk_len = (chunk_len + 3) / 4 * 4;
-    dim3 gridc((unsigned)(TBL_W * nchunks)), b1024(1024), b256(256);
-    uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + (size_t)TBL_W * nchunks * TBL_RANGES;  // 247 * 512 + 513 words <= cap_hist
+    dim3 gridc((unsigned)(tp.W * nchunks)), b1024(1024), b256(256);
+    uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + (size_t)tp.W * nchunks * tp.ranges;  // <= 255 * 512 + 513 words <= cap_hist
+    // chain bound per lane of the bucket kernel: the W n additions over the chip's 2048 x 64 lanes, in one round
     uint32_t kmax = KMAX;
-    HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist);
-    uint32_t *rtotal = cstart + TBL_RANGES + 1;
-    HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(TBL_RANGES), b256, 0, chist, (uint32_t)(TBL_W * nchunks), rtotal);
-    HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(TBL_RANGES), 0, rtotal, cstart);
+    if (ctx->task_len > 0) kmax = (uint32_t)ctx->task_len;
+    else if (entries <= (size_t)16 * 131072) kmax = 16;
+    else if (entries <= (size_t)32 * 131072) kmax = 32;
+    HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, tp, chist);
+    uint32_t *rtotal = cstart + tp.ranges + 1;
+    HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(tp.ranges), b256, 0, chist, (uint32_t)(tp.W * nchunks), tp.ranges, rtotal);
+    HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(tp.ranges), 0, rtotal, cstart);
     HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
-                (uint32_t)ctx->n, base_off, ws.d_presort, ws.d_fine16);
-    HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(TBL_RANGES), b1024, TBL_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, ws.d_counts,
+                (uint32_t)ctx->n, base_off, tp, ws.d_presort, ws.d_fine16);
+    HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(tp.ranges), b1024, TBL_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, tp, ws.d_counts,
                 ws.d_starts, ws.d_ntask, ws.d_toff, ws.d_task_g, ws.d_biglist, ws.d_meta, ws.d_sorted);
-    uint32_t total = TBL_B;
+    uint32_t total = tp.B;
     size_t max_tasks = (size_t)total + entries / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
@@ -1550,21 +1594,22 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
                 ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 total, 512u, ws.d_buckets);
-    // window sums: the 2^19 buckets as 16 virtual windows of 2^15 (8 buckets per lane, 64 segments of 512 buckets each)
-    uint32_t L = 8, nseg = 64;
-    if (ctx->reduce_span == 16 || ctx->reduce_span == 32 || ctx->reduce_span == 64) { L = (uint32_t)ctx->reduce_span; nseg = 512 / L; }
+    // window sums: the buckets as tp.vw virtual windows of 2^vw_bits, 64 segments each (c = 20: 8 buckets per lane; c = 17: 1)
+    uint32_t vwB = 1u << tp.vw_bits;
+    uint32_t L = vwB / 4096 ? vwB / 4096 : 1, nseg = vwB / (64 * L);
+    if (tp.vw_bits == 15 && (ctx->reduce_span == 16 || ctx->reduce_span == 32 || ctx->reduce_span == 64)) { L = (uint32_t)ctx->reduce_span; nseg = 512 / L; }
     int logL = 0;
     while ((1u << logL) < L) logL++;
-    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(TBL_VW * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, 32768u, L, logL,
+    HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(tp.vw * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, vwB, L, logL,
                 nseg, ws.d_seg);
     {
-        int rc = quad_final_enqueue(ctx, ws, TBL_VW, nseg, logL + 6, ws.d_winsum + 12 * TBL_VW);
+        int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, ws.d_winsum + 12 * tp.vw);
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)2 * TBL_VW * 96, hipMemcpyDeviceToHost, s));
+    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
     MsmPlan p;
-    p.c = TBL_C; p.W = TBL_W; p.B = TBL_B; p.batch = 1; p.w0 = 0; p.w1 = TBL_W; p.table_vw = (int)TBL_VW;
+    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = 1; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
     ws.plan = p;
     return HALO_OK;
 }
@@ -1728,7 +1773,7 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
     for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
     if (p.W == 0) return;
     if (p.table_vw > 0) {
-        // virtual window v holds the buckets v 2^15 + 1 .. (v + 1) 2^15: sum_v [ T_v + v 2^15 S_v ]
+        // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ]
         int V = p.table_vw;
         host::Point acc = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
         for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * (size_t)v);
@@ -1736,7 +1781,7 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
             run = run + host::Point::load(ws.h_winsum + 12 * (size_t)(V + v));
             tot = tot + run;
         }
-        for (int k = 0; k < 15 && !tot.is_inf(); ++k) tot = tot.dbl();
+        for (int k = 0; k < p.table_vw_bits && !tot.is_inf(); ++k) tot = tot.dbl();
         out[0] = acc + tot;
         return;
     }

@@ -418,26 +418,41 @@ def test_msm_table_pipeline_equals_general(hal):
         c.close()
 
 
-def test_msm_table_top_window_edges(hal):
-    """The table pipeline recodes s + (i mod 31) r when the scalar's top window (bits 240..) is in 1..2^14 -- the same
-    point, since every base has order r.  Scalars around each edge of that rule, given as plain 256-bit integers
-    (scalars_are_mont = 0; values in [r, 2^255) included: the window walk takes them as they are), must give what the general
-    pipeline gives, whose digits are untouched."""
+@pytest.mark.parametrize("n", [1 << 20, 1 << 17, (1 << 18) + 4096, 1 << 19])
+def test_msm_table_top_window_edges(hal, n):
+    """The table pipeline's plans: keys of >= 2^20 points recode s + (i mod 31) r when the scalar's top window (bits 240..)
+    is in 1..2^14 -- the same point, since every base has order r; keys of 2^17 .. 2^19 points use 15 windows of 17 bits
+    and recode a scalar >= 2^254 as r - s with flipped signs.  Scalars around each edge of both rules, given as plain
+    256-bit integers (scalars_are_mont = 0; values in [r, 2^255) included: the window walk takes them as they are), must
+    give what the general pipeline gives, whose digits are untouched."""
     import torch
-    n = 1 << 20
     c = hal.Context(urs_n=n)
     try:
         r = pm.R_ORDER
         edge = [0, 1, (1 << 240) - 1, 1 << 240, (1 << 240) + 1, (16384 << 240) - 1, 16384 << 240, (16384 << 240) + 12345, r - 1, r, r + 1,
-                16385 << 240, (1 << 255) - 19, (1 << 20) - 1, 1 << 19, (1 << 19) + 1, (1 << 239) + (1 << 19)]
+                16385 << 240, (1 << 255) - 19, (1 << 20) - 1, 1 << 19, (1 << 19) + 1, (1 << 239) + (1 << 19),
+                (1 << 254) - 1, 1 << 254, (1 << 254) + 1, r - (1 << 16), r - (1 << 16) - 1, r + (1 << 100), (1 << 17) - 1, 1 << 16, (1 << 16) + 1,
+                (1 << 238) - 1, 1 << 238, ((1 << 16) - 1) << 238, (1 << 254) - (1 << 237)]
         rng = np.random.default_rng(7)
-        vals = [edge[int(k)] for k in rng.integers(0, len(edge), size=n)]
-        raw = np.zeros((n, 4), dtype=np.uint64)
-        for limb in range(4):
-            raw[:, limb] = np.array([(v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64)
+        table = np.array([[(v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF for limb in range(4)] for v in edge], dtype=np.uint64)
+        raw = table[rng.integers(0, len(edge), size=n)]
+        raw[::2] = rng.integers(0, 1 << 64, size=(n // 2, 4), dtype=np.uint64)  # every other scalar uniform below 2^254:
+        raw[::2, 3] &= np.uint64((1 << 62) - 1)                                    # buckets of every size
+        raw = np.ascontiguousarray(raw)
+        vals = [sum(int(raw[k, limb]) << (64 * limb) for limb in range(4)) for k in range(1 << 12)]
         d = torch.from_numpy(raw.view(np.int64)).cuda()
         c.set_table_mode(-1); a = c.msm_dev(d.data_ptr(), n, mont=False)
+        a2 = c.msm_dev(d.data_ptr(), n, mont=False)                # graph replay
+        c.prof_enable(True); c.prof_reset()
+        a3 = c.msm_dev(d.data_ptr(), n, mont=False)
+        assert "k_tmsm_recode" in c.prof(), "the table pipeline did not run"
+        c.prof_enable(False)
         c.set_table_mode(0); b = c.msm_dev(d.data_ptr(), n, mont=False)
+        assert a.tolist() == b.tolist() == a2.tolist() == a3.tolist()
+        # a stretch that does not start at 0 (at least half the key: still the table)
+        off, m = 1028, n - 4096
+        c.set_table_mode(-1); a = c.msm_dev(d.data_ptr() + off * 32, m, off=off, mont=False)
+        c.set_table_mode(0); b = c.msm_dev(d.data_ptr() + off * 32, m, off=off, mont=False)
         assert a.tolist() == b.tolist()
         # and a slice small enough for the oracle: the same values reduced mod r, in Montgomery form
         m = 1 << 12
