@@ -245,7 +245,9 @@ int halo_set_reduce_span(halo_ctx *ctx, int span);
 int halo_set_sort_mode(halo_ctx *ctx, int mode);
 /* MSM tuning: fixed-base tables.  -1 (default): an MSM of n >= 2^20 points over the context's own key uses the table
  * T[w][i] = 2^(20 w) G_i (13 x 128 bytes per point of the key, built on the first such MSM): 13 instead of 16 mixed
- * additions per point and one shared set of 2^19 buckets.  0: never (no table memory).  Results are identical. */
+ * additions per point and one shared set of 2^19 buckets.  A context whose key has 2^17 .. 2^20 - 1 points builds
+ * T[w][i] = 2^(17 w) G_i instead (15 x 128 bytes per point, 15 additions, 2^16 buckets) for MSMs over at least half of
+ * its key.  0: never (no table memory).  Results are identical. */
 int halo_set_table_mode(halo_ctx *ctx, int mode);
 /* MSM tuning: the 4-launch pipeline for MSMs of up to 2^16 points (sort per window in LDS, quad-parallel window sums):
  * -1 automatic (default), 0 never (the general pipeline at every size).  Results are identical. */
