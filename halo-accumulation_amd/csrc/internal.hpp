@@ -69,6 +69,7 @@ struct MsmPlan {
     int w0, w1;   // windows [w0, w1) of 0..W are computed (a window-sharded partial); the result carries 2^(c*w0)
     int table_vw = 0;  // > 0: the fixed-base table pipeline ran; h_winsum holds table_vw weighted sums, then table_vw plain sums
     int table_vw_bits = 15;  // log2 of the buckets per virtual window
+    int table_pieces = 1;    // a large table MSM runs as this many consecutive pieces: 2 * table_vw sums each
 };
 constexpr int MSM_MAX_BATCH = 8;
 // fixed-base table plan of a context (msm.hip: table_plan)
@@ -285,7 +286,7 @@ int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const u
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
-int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum_plain);
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain);
 int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
                  uint32_t kmax);
 int smsm_prepare();

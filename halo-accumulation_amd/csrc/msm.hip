@@ -437,6 +437,11 @@ __global__ __launch_bounds__(1024) void k_msm_fine_sort(const uint32_t *__restri
 //     2^16 buckets, n / 2048 coarse ranges (so that a range's 15 n / ranges entries fit the fine sort's LDS stage), 16 virtual
 //     windows of 2^12 -- 15 n additions against 16 n, an eighth of the buckets of the general plan's 16 x 2^15.
 constexpr uint32_t TBL_MAX_RANGES = 512;
+// An MSM of more points than this runs as consecutive pieces on its stream (c = 20 plan): a coarse range of a piece then
+// holds <= 13 * 1310720 / 512 = 33 k entries and fits the fine sort's LDS stage, buckets keep ~26-33 entries (one task
+// each) -- at 2^21 .. 2^24 points in one piece the fine sort placed entries straight to HBM (0.36 ms at 2^21, 8.5 ms at
+// 2^24) and k_msm_combine folded 2 .. 8 partials per bucket.  The pieces' window sums are added on the host.
+constexpr size_t TBL_PIECE = 1310720;
 constexpr uint32_t TDIGIT_NONE = 0xFFFFFFFFu;
 TblPlan table_plan(size_t key_n) {
     TblPlan t{};
@@ -1381,6 +1386,10 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     }
     need.hist = (size_t)256 * 32768 + need.counts;  // W * nchunks <= 256 blocks of B <= 32768 counters
     need.windows = 64;
+    {   // the table pipeline runs a large MSM in pieces and keeps 2 x 16 window sums per piece
+        size_t pieces = (n + TBL_PIECE - 1) / TBL_PIECE;
+        if (32 * pieces > need.windows) need.windows = 32 * pieces;
+    }
     alloc_epoch_bump(ctx);
     return workspace_alloc(ctx->wss[slot], need);
 }
@@ -1545,16 +1554,34 @@ static int table_build(halo_ctx *ctx) {
     ctx->tbl = tp;
     return HALO_OK;
 }
-// can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key that is at least
-// half of it (the plan's bucket count and coarse ranges are sized for the key), indices within 31 bits.
+// can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key -- of at least 2^20
+// points, or at least half of a smaller key (that plan's coarse ranges are sized for the key) -- indices within 31 bits.
 static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n) {
     if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.count != 1 || members.parts != 1) return false;
     TblPlan tp = table_plan(ctx->n);
     size_t least = tp.c == 20 ? ((size_t)1 << 20) : ((size_t)1 << 17);
-    if (ctx->n < least || n < least || 2 * n < ctx->n || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
+    if (ctx->n < least || n < least || (tp.c != 20 && 2 * n < ctx->n) || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, int piece);
 static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
+    const TblPlan tp = ctx->tbl;
+    size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
+    if (2 * tp.vw * pieces > ws.cap_windows) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+    size_t len = ((n + pieces - 1) / pieces + 3) / 4 * 4, off = 0;
+    for (size_t k = 0; k < pieces; ++k, off += len) {
+        size_t m = off + len <= n ? len : n - off;  // (n and len are multiples of 4)
+        int rc = tmsm_enqueue_piece(ctx, ws, d_bases + AFF_STRIDE * off, d_scalars + 4 * off, mont, m, (int)k);
+        if (rc) return rc;
+    }
+    MsmPlan p;
+    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = 1; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
+    p.table_pieces = (int)pieces;
+    ws.plan = p;
+    return HALO_OK;
+}
+// one piece: window sums to slot `piece` of d_winsum / h_winsum (tp.vw weighted sums, then tp.vw plain sums)
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, int piece) {
     const TblPlan tp = ctx->tbl;
     size_t entries = (size_t)tp.W * n;
     if (n > ws.cap_n || entries > ws.cap_sorted || tp.B > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
@@ -1602,15 +1629,13 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(tp.vw * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, vwB, L, logL,
                 nseg, ws.d_seg);
+    uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
     {
-        int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, ws.d_winsum + 12 * tp.vw);
+        int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, d_out, d_out + 12 * tp.vw);
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
-    MsmPlan p;
-    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = 1; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
-    ws.plan = p;
+    HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * 2 * tp.vw * 12, d_out, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
     return HALO_OK;
 }
 
@@ -1726,7 +1751,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(Wt * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
     {
-        int rc = quad_final_enqueue(ctx, ws, (uint32_t)Wt, nseg, logL + 6, nullptr);
+        int rc = quad_final_enqueue(ctx, ws, (uint32_t)Wt, nseg, logL + 6, ws.d_winsum, nullptr);
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
@@ -1776,9 +1801,10 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
         // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ]
         int V = p.table_vw;
         host::Point acc = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
-        for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * (size_t)v);
+        for (int k = 0; k < p.table_pieces; ++k)  // the pieces of a large MSM add up window by window
+            for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * V + v));
         for (int v = V - 1; v >= 1; --v) {  // tot = sum_v v S_v by running sums
-            run = run + host::Point::load(ws.h_winsum + 12 * (size_t)(V + v));
+            for (int k = 0; k < p.table_pieces; ++k) run = run + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * V + V + v));
             tot = tot + run;
         }
         for (int k = 0; k < p.table_vw_bits && !tot.is_inf(); ++k) tot = tot.dbl();

@@ -538,10 +538,10 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
 // The last step of the sorted pipelines of msm.hip as well: the (S, T) records k_msm_reduce1 left per segment (nseg <= 64
 // per window, 2^k buckets each) -> window sums.  A chain of ~20 dependent point operations run by Wt blocks: the quad
 // form takes 80 us where one wave per window took 130.
-int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum_plain) {
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain) {
     int live_seg = 1;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
-    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, k, live_seg, ws.d_winsum, winsum_plain);
+    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, k, live_seg, winsum, winsum_plain);
     return HALO_OK;
 }
 
