@@ -194,8 +194,12 @@ def main():
     if rank == 0:
         dom = "k_msm_accumulate" if "k_msm_accumulate" in prof_solo else "k_smsm_accumulate"  # n <= 2^16: the small-MSM pipeline
         acc_ms, acc_cnt = prof_solo.get(dom, (0.0, 0))
-        kern_s = acc_ms / max(acc_cnt, 1) * 1e-3
+        # per launch sequence: an MSM of more than 1.3 M points runs the kernel once per piece, and the
+        # algorithmic bytes below are those of the whole launch
+        n_launches = max(prof_steps // batch, 1)
+        kern_s = acc_ms / n_launches * 1e-3
         ovl_ms, ovl_cnt = prof.get(dom, (0.0, 0))
+        ovl_cnt = n_launches if ovl_cnt else 0
         # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
         # index block or their 1/parts window share on this rank)
         alg_bytes = batch * (96 * (hi - lo) // parts + 64)
