@@ -594,7 +594,7 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
                                                               const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
                                                               uint32_t table_n, uint32_t base_off, TblPlan tp, uint32_t *__restrict__ presort,
                                                               uint16_t *__restrict__ presort_fine) {
-    __shared__ uint32_t cur[TBL_MAX_RANGES], tcount[TBL_MAX_RANGES], toff[TBL_MAX_RANGES];
+    __shared__ uint32_t cur[TBL_MAX_RANGES], tcount[TBL_MAX_RANGES], toff[TBL_MAX_RANGES], wsum[TBL_MAX_RANGES / 64];
     const uint32_t ranges = tp.ranges, fmask = (1u << tp.fbits) - 1u;
     __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
     __shared__ uint16_t t_fine[TBL_TILE];
@@ -617,12 +617,21 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
 #pragma unroll
         for (int k = 0; k < 8; k++) rank[k] = v[k] != TDIGIT_NONE ? atomicAdd(&tcount[(v[k] & (tp.B - 1u)) >> tp.fbits], 1u) : 0u;
         __syncthreads();
-        if (tid < ranges) toff[tid] = tcount[tid];
-        __syncthreads();
-        for (uint32_t off = 1; off < ranges; off <<= 1) {  // inclusive scan of the tile's counts (threads 0..511)
-            uint32_t o = (tid < ranges && tid >= off) ? toff[tid - off] : 0u;
+        {   // inclusive scan of the tile's counts: shuffles within a wave, the <= 8 wave totals through LDS -- two barriers
+            // (a Hillis-Steele pass over LDS took 18, per tile, for sixteen waves)
+            uint32_t x = tid < ranges ? tcount[tid] : 0u;
+            uint32_t lane = tid & 63u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = (uint32_t)__shfl_up((int)x, off, 64);
+                if (lane >= (uint32_t)off) x += o;
+            }
+            if (lane == 63 && tid < TBL_MAX_RANGES) wsum[tid >> 6] = x;
             __syncthreads();
-            if (tid < ranges) toff[tid] += o;
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t wv = 0; wv < TBL_MAX_RANGES / 64; wv++) before += (wv < (tid >> 6)) ? wsum[wv] : 0u;
+            if (tid < ranges) toff[tid] = x + before;
             __syncthreads();
         }
         uint32_t total = toff[ranges - 1];
