@@ -36,8 +36,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--depth", type=int, default=4, help="launch sequences in flight (1..4)")
     ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one or two GPUs, 4 on more)")
-    ap.add_argument("--shard", choices=["window", "index"], default="window",
-                    help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index")
+    ap.add_argument("--shard", choices=["window", "index", "auto"], default="auto",
+                    help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index; "
+                         "auto = windows up to n = 2^21, index blocks from 2^22 (a rank's block is then a table-pipeline MSM)")
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
@@ -71,7 +72,10 @@ def main():
     from halo_accumulation_amd.sharded import ShardedMsm, shard_range
 
     n = 1 << args.log_n
-    batch = args.batch if args.batch > 0 else (1 if world <= 2 else 4)  # measured optimum per rank (tools/sweep_batch.py)
+    if args.shard == "auto":
+        args.shard = "window" if args.log_n < 22 else "index"
+    # MSMs per launch: measured optimum per rank (tools/sweep_batch.py); the table pipeline of large index blocks takes one
+    batch = args.batch if args.batch > 0 else (1 if world <= 2 or (args.shard == "index" and args.log_n >= 22) else 4)
     window_mode = world > 1 and args.shard == "window"
     if window_mode:
         # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes
