@@ -418,13 +418,14 @@ def test_msm_table_pipeline_equals_general(hal):
         c.close()
 
 
-@pytest.mark.parametrize("n", [1 << 20, 1 << 17, (1 << 18) + 4096, 1 << 19])
+@pytest.mark.parametrize("n", [1 << 20, 1 << 17, (1 << 18) + 4096, 1 << 19, (1 << 20) + (1 << 18) + 4100])
 def test_msm_table_top_window_edges(hal, n):
     """The table pipeline's plans: keys of >= 2^20 points recode s + (i mod 31) r when the scalar's top window (bits 240..)
     is in 1..2^14 -- the same point, since every base has order r; keys of 2^17 .. 2^19 points use 15 windows of 17 bits
     and recode a scalar >= 2^254 as r - s with flipped signs.  Scalars around each edge of both rules, given as plain
     256-bit integers (scalars_are_mont = 0; values in [r, 2^255) included: the window walk takes them as they are), must
-    give what the general pipeline gives, whose digits are untouched."""
+    give what the general pipeline gives, whose digits are untouched.  (The last size runs as two pieces of unequal
+    length: more than 1,310,720 points.)"""
     import torch
     c = hal.Context(urs_n=n)
     try:
