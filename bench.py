@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="MSMs per launch sequence (1..8; 0 = 1 on one or two GPUs, 4 on more)")
     ap.add_argument("--shard", choices=["window", "index", "auto"], default="auto",
                     help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index; "
-                         "auto = windows up to n = 2^21, index blocks from 2^22 (a rank's block is then a table-pipeline MSM)")
+                         "auto = index blocks while a rank's block has >= 2^17 points (a fixed-base-table MSM), else windows")
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
@@ -72,10 +72,19 @@ def main():
     from halo_accumulation_amd.sharded import ShardedMsm, shard_range
 
     n = 1 << args.log_n
+    per_rank = n // world
     if args.shard == "auto":
-        args.shard = "window" if args.log_n < 22 else "index"
-    # MSMs per launch: measured optimum per rank (tools/sweep_batch.py); the table pipeline of large index blocks takes one
-    batch = args.batch if args.batch > 0 else (1 if world <= 2 or (args.shard == "index" and args.log_n >= 22) else 4)
+        # an index block of >= 2^17 points is a fixed-base-table MSM on its rank (small-key plan below 2^20
+        # points, in batches; pieces above 1.3 M); smaller blocks would be latency-bound: window shards of the full MSM then
+        args.shard = "index" if per_rank >= (1 << 17) else "window"
+    # MSMs per launch, measured per rank on one GPU (tools/time_table_batch.py, tools/sweep_batch.py): index blocks go through
+    # the table plan as batches of 8 / 4 / 2 at 2^17 / 2^18 / 2^19 points (count x coarse ranges <= 512), one per launch from 2^20
+    if args.batch > 0:
+        batch = args.batch
+    elif world > 1 and args.shard == "index":
+        batch = 8 if per_rank < (1 << 18) else 4 if per_rank < (1 << 19) else 2 if per_rank < (1 << 20) else 1
+    else:
+        batch = 1 if world <= 2 else 4
     window_mode = world > 1 and args.shard == "window"
     if window_mode:
         # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes
@@ -220,7 +229,11 @@ def main():
         # kernel's hot path (counted in the gfx950 ISA), one per point per window; the issue peak is the measured
         # 5.26 cycles per wave-instruction (profiles/r01_microbench_instr_throughput.txt) on 4 SIMDs per CU
         props = torch.cuda.get_device_properties(gpu)
-        plan_w = (13 if world == 1 else 16) if args.log_n >= 20 else None  # fixed-base tables (c = 20) on one GPU, c = 16 window shards on more
+        # additions per point: 13 with the c = 20 table (>= 2^20 points on this rank), 15 with the small-key table (index
+        # blocks of 2^17 .. 2^19 points), 16 for window shards of the general 16-window plan
+        plan_w = None
+        if args.log_n >= 20:
+            plan_w = 16 if window_mode else (13 if hi - lo >= (1 << 20) else 15 if hi - lo >= (1 << 17) else None)
         valu = None
         if plan_w and kern_s > 0:
             wave_mads = batch * (hi - lo) * plan_w / parts * 1143 / 64
@@ -238,8 +251,9 @@ def main():
                                     else "block index shard per rank + %s all-gather of 96 B partials" % coll_name),
                        "collective_backend": backend_name, "world_size": world_reported, "distinct_gpus": distinct_gpus,
                        "msms_per_launch": batch, "launches_in_flight": args.depth,
-                       "window_bits": "one GPU: 20 with fixed-base tables over the context's key (13 windows, one set of 2^19 buckets); "
-                                      "N > 1: 16 (window shards of the 16-window MSM)"},
+                       "window_bits": "a rank's block of >= 2^20 points: 20 with fixed-base tables over the context's key (13 windows, one set "
+                                      "of 2^19 buckets); index blocks of 2^17..2^19 points: 17 (15 windows, 2^16 buckets per MSM of a batch); "
+                                      "window shards: 16 (16-window general plan)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),

@@ -69,7 +69,8 @@ struct MsmPlan {
     int w0, w1;   // windows [w0, w1) of 0..W are computed (a window-sharded partial); the result carries 2^(c*w0)
     int table_vw = 0;  // > 0: the fixed-base table pipeline ran; h_winsum holds table_vw weighted sums, then table_vw plain sums
     int table_vw_bits = 15;  // log2 of the buckets per virtual window
-    int table_pieces = 1;    // a large table MSM runs as this many consecutive pieces: 2 * table_vw sums each
+    int table_pieces = 1;    // a large table MSM runs as this many consecutive pieces: 2 * table_sets * table_vw sums each
+    int table_sets = 1;      // bucket sets side by side in a batched table launch (members, rounded up to a power of two)
 };
 constexpr int MSM_MAX_BATCH = 8;
 // fixed-base table plan of a context (msm.hip: table_plan)

@@ -470,10 +470,14 @@ __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__
 }
 
 // signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
-__global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict__ scalars, int mont, uint32_t n, TblPlan tp, uint32_t *__restrict__ digits,
+// blockIdx.y = member of a batched launch (small-key plan): its digits go to rows [member W, (member + 1) W) and carry
+// member * B on top of the bucket number, so that every later kernel sees one MSM with count * B buckets.
+struct TblScalars { const uint64_t *p[MSM_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void k_tmsm_recode(TblScalars members, int mont, uint32_t n, TblPlan tp, uint32_t *__restrict__ digits,
                                                      uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
-    if (blockIdx.x == 0) {
+    const uint64_t *__restrict__ scalars = members.p[blockIdx.y];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         meta[threadIdx.x] = 0;
         for (int k = 0; k < 4; k++) { zero_b[threadIdx.x + 256 * k] = 0; zero_t[threadIdx.x + 256 * k] = 0; }
     }
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(const uint64_t *__restrict_
     uint32_t carry = 0;
     for (int w = 0; w < tp.W; w++) {
         Digit d = next_digit(my, w, tp.c, tp.B, carry);
-        digits[(size_t)w * n + i] = d.mag ? ((d.mag - 1) | ((d.neg ^ flip) << 31)) : TDIGIT_NONE;
+        digits[((size_t)blockIdx.y * tp.W + w) * n + i] = d.mag ? ((d.mag - 1 + blockIdx.y * tp.B) | ((d.neg ^ flip) << 31)) : TDIGIT_NONE;
     }
 }
 // block (w, chunk): counts of the 512 coarse ranges, one private row per wave
@@ -598,11 +602,11 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
     const uint32_t ranges = tp.ranges, fmask = (1u << tp.fbits) - 1u;
     __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
     __shared__ uint16_t t_fine[TBL_TILE];
-    uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, tid = threadIdx.x;
+    uint32_t row = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, tid = threadIdx.x;  // row = member * W + w
     if (tid < ranges) cur[tid] = cstart[tid] + chist[(size_t)blockIdx.x * ranges + tid];
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
-    const uint32_t *dg = digits + (size_t)w * n;
-    uint32_t tbase = w * table_n + base_off;
+    const uint32_t *dg = digits + (size_t)row * n;
+    uint32_t tbase = (row % (uint32_t)tp.W) * table_n + base_off;
     for (uint32_t t0 = lo; t0 < hi; t0 += TBL_TILE) {
         if (tid < ranges) tcount[tid] = 0;
         __syncthreads();
@@ -1438,6 +1442,13 @@ static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) {
 static bool batch_need(const halo_ctx *ctx, const MsmWorkspace &ws, size_t n, int count, WorkspaceNeed &need) {
     MsmPlan p = msm_plan(n, ctx->window_bits);
     size_t Wt = (size_t)p.W * count, total = Wt * p.B, sorted = n * Wt;
+    if (count > 1 && ctx->n < ((size_t)1 << 20) && ctx->n >= ((size_t)1 << 17)) {  // room for a batch through the small-key table plan
+        size_t sets = 1;
+        while (sets < (size_t)count) sets <<= 1;
+        if (Wt < 32 * sets) Wt = 32 * sets;          // 2 x 16 window sums per bucket set
+        if (sorted < n * 30 * (size_t)count) sorted = n * 30 * (size_t)count;  // 15 rows of u32 digits per member (d_canon holds 2 bytes per entry)
+        if (total < sets << 16) total = sets << 16;
+    }
     size_t hist = (Wt > 256 ? Wt : 256) * (size_t)p.B;
     size_t tasks = total + sorted / msm_kmax(ctx, n) + 1;
     bool grow = n > ws.cap_n || total > ws.cap_counts || sorted > ws.cap_sorted || hist > ws.cap_hist || Wt > ws.cap_windows ||
@@ -1566,48 +1577,73 @@ static int table_build(halo_ctx *ctx) {
 // can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key -- of at least 2^20
 // points, or at least half of a smaller key (that plan's coarse ranges are sized for the key) -- indices within 31 bits.
 static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n) {
-    if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.count != 1 || members.parts != 1) return false;
+    if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.parts != 1) return false;
     TblPlan tp = table_plan(ctx->n);
+    if (members.count != 1) {  // batches: small-key plan only, members over the same points, count * ranges coarse ranges at most 512
+        uint32_t cpow = 1;
+        while ((int)cpow < members.count) cpow <<= 1;
+        if (tp.c == 20 || cpow * tp.ranges > TBL_MAX_RANGES) return false;
+        for (int b = 1; b < members.count; ++b)
+            if (members.base_off[b] != members.base_off[0]) return false;
+    }
     size_t least = tp.c == 20 ? ((size_t)1 << 20) : ((size_t)1 << 17);
     if (ctx->n < least || n < least || (tp.c != 20 && 2 * n < ctx->n) || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
-static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, int piece);
-static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n) {
-    const TblPlan tp = ctx->tbl;
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece);
+// A batch is about throughput: its window sums take 2^15-bucket virtual windows (8 buckets per lane) like the large plan --
+// with 2^12 (one bucket per lane: the short chain a single MSM wants) the wave-wide step of k_msm_reduce1 cost as many
+// instructions as the bucket kernel itself.
+static TblPlan table_launch_plan(const halo_ctx *ctx, int count) {
+    TblPlan tp = ctx->tbl;
+    if (count > 1 && tp.vw_bits < 15 && tp.B >= (1u << 15)) { tp.vw_bits = 15; tp.vw = tp.B >> 15; }
+    return tp;
+}
+static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
+    const TblPlan tp = table_launch_plan(ctx, members.count);
     size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
-    if (2 * tp.vw * pieces > ws.cap_windows) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+    uint32_t cpow = 1;  // a batch (small-key plan, one piece) lays its members' bucket sets side by side: a power of two of them
+    while ((int)cpow < members.count) cpow <<= 1;
+    if (2 * tp.vw * pieces * cpow > ws.cap_windows) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
     size_t len = ((n + pieces - 1) / pieces + 3) / 4 * 4, off = 0;
     for (size_t k = 0; k < pieces; ++k, off += len) {
         size_t m = off + len <= n ? len : n - off;  // (n and len are multiples of 4)
-        int rc = tmsm_enqueue_piece(ctx, ws, d_bases + AFF_STRIDE * off, d_scalars + 4 * off, mont, m, (int)k);
+        int rc = tmsm_enqueue_piece(ctx, ws, d_bases + AFF_STRIDE * off, members, off, mont, m, (int)k);
         if (rc) return rc;
     }
     MsmPlan p;
-    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = 1; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
+    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = members.count; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
     p.table_pieces = (int)pieces;
+    p.table_sets = (int)cpow;
     ws.plan = p;
     return HALO_OK;
 }
-// one piece: window sums to slot `piece` of d_winsum / h_winsum (tp.vw weighted sums, then tp.vw plain sums)
-static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, int piece) {
-    const TblPlan tp = ctx->tbl;
-    size_t entries = (size_t)tp.W * n;
-    if (n > ws.cap_n || entries > ws.cap_sorted || tp.B > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+// one piece: window sums to slot `piece` of d_winsum / h_winsum (sets * vw weighted sums, then sets * vw plain sums)
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece) {
+    TblPlan tp = table_launch_plan(ctx, members.count);
+    uint32_t cpow = 1;
+    while ((int)cpow < members.count) cpow <<= 1;
+    size_t entries = (size_t)tp.W * n * members.count;
+    if (n > ws.cap_n || entries > ws.cap_sorted || (size_t)tp.B * cpow > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
     if (!ws.d_fine16) {
         alloc_epoch_bump(ctx);
         HALO_HIP(hipMalloc(&ws.d_fine16, ws.cap_sorted * 2));
     }
     hipStream_t s = ctx->stream;
     uint32_t base_off = (uint32_t)((d_bases - ctx->d_bases) / AFF_STRIDE);
-    uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * W n bytes <= 2 * 32 n
-    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_scalars, mont ? 1 : 0, (uint32_t)n, tp, d_digits,
-                ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
-    uint32_t nchunks = 256u / (uint32_t)tp.W;  // 19 (17) chunks per window: about one block per CU
+    uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * W n bytes per member <= 2 * cap_sorted
+    TblScalars srcs{};
+    for (int b = 0; b < members.count; ++b) srcs.p[b] = members.scalars[b] + 4 * soff;
+    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256), (unsigned)members.count), dim3(256), 0, srcs, mont ? 1 : 0, (uint32_t)n,
+                tp, d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
+    // from here on: ONE MSM of rows = count * W digit rows over sets * B buckets
+    const uint32_t rows = (uint32_t)tp.W * (uint32_t)members.count;
+    tp.B *= cpow; tp.ranges *= cpow; tp.vw *= cpow;
+    uint32_t nchunks = 256u / rows;  // 19 (17) chunks per window: about one block per CU
     uint32_t chunk_len = (uint32_t)((n + nchunks - 1) / nchunks);
     chunk_len = (chunk_len + 3) / 4 * 4;
-    dim3 gridc((unsigned)(tp.W * nchunks)), b1024(1024), b256(256);
-    uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + (size_t)tp.W * nchunks * tp.ranges;  // <= 255 * 512 + 513 words <= cap_hist
+    dim3 gridc((unsigned)(rows * nchunks)), b1024(1024), b256(256);
+    uint32_t *chist = ws.d_hist, *cstart = ws.d_hist + (size_t)rows * nchunks * tp.ranges;  // <= 255 * 512 + 513 words <= cap_hist
     // chain bound per lane of the bucket kernel: the W n additions over the chip's 2048 x 64 lanes, in one round
     uint32_t kmax = KMAX;
     if (ctx->task_len > 0) kmax = (uint32_t)ctx->task_len;
@@ -1615,7 +1651,7 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     else if (entries <= (size_t)32 * 131072) kmax = 32;
     HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, tp, chist);
     uint32_t *rtotal = cstart + tp.ranges + 1;
-    HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(tp.ranges), b256, 0, chist, (uint32_t)(tp.W * nchunks), tp.ranges, rtotal);
+    HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(tp.ranges), b256, 0, chist, rows * nchunks, tp.ranges, rtotal);
     HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(tp.ranges), 0, rtotal, cstart);
     HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
                 (uint32_t)ctx->n, base_off, tp, ws.d_presort, ws.d_fine16);
@@ -1653,7 +1689,7 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
 // only the recode (one scalar array per member) and the scatter (one base offset per member) know better.
 int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
-    if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members.scalars[0], mont, n);
+    if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members, mont, n);
     MsmPlan p = msm_plan(n, ctx->window_bits);
     p.batch = members.count;
     p.w0 = p.W * members.part / members.parts;
@@ -1789,6 +1825,21 @@ void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out) {
     MsmPlan p = ws.plan;
     *out = host::Point::infinity();
     if (p.W == 0) return;
+    if (p.table_vw > 0) {
+        // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ];
+        // a piece (large MSM) or a batch stores sets * V weighted sums, then sets * V plain sums; member b owns set b
+        int V = p.table_vw, A = p.table_sets * V;
+        host::Point acc = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
+        for (int k = 0; k < p.table_pieces; ++k)  // the pieces of a large MSM add up window by window
+            for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * A + (size_t)b * V + v));
+        for (int v = V - 1; v >= 1; --v) {  // tot = sum_v v S_v by running sums
+            for (int k = 0; k < p.table_pieces; ++k) run = run + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * A + A + (size_t)b * V + v));
+            tot = tot + run;
+        }
+        for (int k = 0; k < p.table_vw_bits && !tot.is_inf(); ++k) tot = tot.dbl();
+        *out = acc + tot;
+        return;
+    }
     int Wm = p.w1 - p.w0;
     host::Point acc = host::Point::infinity();
     for (int w = Wm - 1; w >= 0; --w) {
@@ -1808,16 +1859,7 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
     if (p.W == 0) return;
     if (p.table_vw > 0) {
         // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ]
-        int V = p.table_vw;
-        host::Point acc = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
-        for (int k = 0; k < p.table_pieces; ++k)  // the pieces of a large MSM add up window by window
-            for (int v = 0; v < V; ++v) acc = acc + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * V + v));
-        for (int v = V - 1; v >= 1; --v) {  // tot = sum_v v S_v by running sums
-            for (int k = 0; k < p.table_pieces; ++k) run = run + host::Point::load(ws.h_winsum + 12 * ((size_t)k * 2 * V + V + v));
-            tot = tot + run;
-        }
-        for (int k = 0; k < p.table_vw_bits && !tot.is_inf(); ++k) tot = tot.dbl();
-        out[0] = acc + tot;
+        for (int b = 0; b < count; ++b) msm_combine_member(ctx, slot, b, &out[b]);
         return;
     }
     for (int b = 0; b < count; ++b) msm_combine_member(ctx, slot, b, &out[b]);

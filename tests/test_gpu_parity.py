@@ -466,6 +466,47 @@ def test_msm_table_top_window_edges(hal, n):
         c.close()
 
 
+@pytest.mark.parametrize("lg,batch", [(17, 2), (17, 3), (17, 4), (17, 8), (18, 4), (19, 2)])
+def test_msm_table_batch_small_keys(hal, lg, batch):
+    """A batch of MSMs over a key of 2^17 .. 2^19 points goes through the small-key table plan as ONE launch (the members'
+    bucket sets side by side, count * ranges <= 512): every member equals its own single MSM through the general pipeline;
+    one member is all zero, one has scalars >= 2^254."""
+    import torch
+    n = 1 << lg
+    c = hal.Context(urs_n=n)
+    try:
+        sets = []
+        for j in range(batch):
+            d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+            c.rng_scalars_dev(100 + j, n, d.data_ptr())
+            if j == 1: d.zero_()
+            sets.append(d)
+        if batch > 2:
+            rm1 = torch.from_numpy(np.ascontiguousarray(np.tile(orc.fr_to_mont(pm.R_ORDER - 1), (n // 2, 1))).view(np.int64)).cuda()
+            sets[2].view(n, 4)[::2] = rm1
+        ptrs = [d.data_ptr() for d in sets]
+        c.set_table_mode(0)
+        want = [c.msm_dev(p, n).tolist() for p in ptrs]
+        c.set_table_mode(-1)
+        c.msm_dev_batch_begin(0, ptrs, n); got = c.msm_dev_batch_end(0, batch)
+        c.msm_dev_batch_begin(0, ptrs, n); got2 = c.msm_dev_batch_end(0, batch)   # graph capture
+        c.msm_dev_batch_begin(0, ptrs, n); got3 = c.msm_dev_batch_end(0, batch)   # graph replay
+        c.prof_enable(True); c.prof_reset()
+        c.msm_dev_batch_begin(1, ptrs, n); got4 = c.msm_dev_batch_end(1, batch)
+        assert "k_tmsm_recode" in c.prof(), "the table pipeline did not run"
+        c.prof_enable(False)
+        for g in (got, got2, got3, got4):
+            assert [g[j].tolist() for j in range(batch)] == want
+        # a stretch that does not start at 0
+        off, m = 2052, n - 8192
+        c.set_table_mode(0); w2 = [c.msm_dev(p + off * 32, m, off=off).tolist() for p in ptrs]
+        c.set_table_mode(-1)
+        c.msm_dev_batch_begin(0, [p + off * 32 for p in ptrs], m, off=off); g5 = c.msm_dev_batch_end(0, batch)
+        assert [g5[j].tolist() for j in range(batch)] == w2
+    finally:
+        c.close()
+
+
 def test_msm_2_20_linearity(ctx1m):
     """Size-independent property: msm(a) + msm(b) == msm(a + b); msm(k a) == k msm(a)."""
     n = 1 << 20

@@ -21,7 +21,8 @@ export HALO_BENCH_BACKEND=gloo
 for N in 2 4; do
   step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 2> $OUT/bench_gloo$N.err | grep '^{' > $OUT/bench_gloo$N.json || exit 1
 done
-step gloo2_index; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 64 --warmup 8 --shard index 2> $OUT/bench_gloo2_index.err | grep '^{' > $OUT/bench_gloo2_index.json || exit 1
+# (the default of N > 1 is index blocks through the table plan; the other cut, Pippenger windows, explicitly)
+step gloo2_window; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 64 --warmup 8 --shard window 2> $OUT/bench_gloo2_window.err | grep '^{' > $OUT/bench_gloo2_window.json || exit 1
 # BASELINE config 5 shape: n = 2^24 in index shards (two ranks sharing this GPU: 2^23 points each)
 step gloo2_index_2_24; timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 2 --log-n 24 --steps 12 --warmup 2 --shard index --min-seconds 0 2> $OUT/bench_gloo2_index_2_24.err | grep '^{' > $OUT/bench_gloo2_index_2_24.json || exit 1
 unset HALO_BENCH_BACKEND
