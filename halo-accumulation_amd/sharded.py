@@ -9,11 +9,12 @@ The payload is latency-, not bandwidth-bound: one collective per batch of MSMs a
 crosses the fabric.
 
 * index shards (shard_range): rank r owns the index block [r*n/P, (r+1)*n/P) of bases and scalars.
-  Memory and upload traffic are 1/P per rank, but each rank runs a SMALLER Pippenger, which costs more
-  per point (its 2^(c-1) buckets per window are reduced for n/P instead of n points): right for n >= 2^22.
+  Memory and upload traffic are 1/P per rank and the block is a fixed-base-table MSM over the rank's own
+  key (from 2^17 points; below 2^20 points in batches of several MSMs per launch).  What bench.py uses
+  while a rank's block has at least 2^17 points.
 * window shards (window_range, halo_msm_dev_begin_part): every rank keeps the whole key and all scalars
   (160 MiB at n = 2^20 of 288 GiB) and computes the Pippenger windows [r*W/P, (r+1)*W/P) of the full-size
-  MSM: exactly 1/P of the single-GPU bucket work.  This is what bench.py uses for n = 2^20.
+  MSM (general 16-window plan): exactly 1/P of that plan's bucket work.  For blocks too small for a table.
 """
 from __future__ import annotations
 
