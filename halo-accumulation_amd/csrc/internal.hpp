@@ -88,6 +88,7 @@ struct MsmBatch {
     int part = 0, parts = 1;  // window shard: this launch computes windows [part*W/parts, (part+1)*W/parts)
 };
 MsmPlan msm_plan(size_t n, int forced_c);
+uint32_t msm_spread(const MsmPlan &p, uint32_t *top_bit);  // top-window spread of the recode (0: none)
 
 struct MsmWorkspace {
     size_t cap_n = 0;

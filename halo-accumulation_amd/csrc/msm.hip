@@ -63,6 +63,17 @@ MsmPlan msm_plan(size_t n, int forced_c) {
     return p;
 }
 
+// Top-window spread of a plan (k_msm_recode): modulus of k and the top window's first bit; 0 when the plan has fewer than
+// two spare bits (c W - 255) or its top window starts at bit 254 or later (nothing but a carry lands there).
+// Any s < 2^255 < 2 r and k <= mod - 1 give s + k r < (mod + 1) r <= (2^(cW-255) - 1) r < 2^(cW-1).
+uint32_t msm_spread(const MsmPlan &p, uint32_t *top_bit) {
+    int spare = p.c * p.W - 255;
+    *top_bit = (uint32_t)(p.c * (p.W - 1));
+    if (spare < 2 || *top_bit >= 254 || *top_bit < 224) return 0;
+    uint32_t mod = (spare >= 6 ? 64u : (1u << spare)) - 2u;
+    return mod;
+}
+
 // ------------------------------------------------------------------------------ recode
 // Signed digit of window w: v = bits + carry; v > B  =>  v - 2^c (carry 1).  Top window never
 // carries out because c*W >= 256 > 255 bits.  Returns magnitude (0 = skip) and sign.
@@ -90,7 +101,13 @@ constexpr uint32_t KMAX = 64;  // largest task length of the bucket kernel (plan
 // of a batched launch.  A window shard (w0 > 0) does not walk the carry chain from window 0: the carry into w0 is
 // decided by the nearest lower window whose raw digit differs from B (raw < B: 0, raw > B: 1, raw == B: passes on).
 struct MemberScalars { const uint64_t *p[MSM_MAX_BATCH]; };
+// spread_mod > 0: the plan's top window holds only a few scalar bits (c = 10: 5 of 10), so its n digits would pile into a
+// handful of buckets.  Every base of this library has order r (Pallas has cofactor 1), so s + k r gives the same point:
+// k = i mod spread_mod makes the top digit floor((s + k r) / 2^top_bit) uniform over the window's buckets, at no cost
+// (msm_spread below: s + k r < 2^(c W - 1), the top window still cannot carry out).  Scalars with an empty top window
+// (zero, short challenges) and unreduced inputs >= 2^255 stay as they are.
 __global__ __launch_bounds__(256) void k_msm_recode(MemberScalars scalars, int mont, uint32_t n, int c, int w0, int w1, uint32_t B,
+                                                    uint32_t spread_mod, uint32_t top_bit,
                                                     uint16_t *__restrict__ digits, uint32_t *__restrict__ meta,
                                                     uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
@@ -113,6 +130,18 @@ __global__ __launch_bounds__(256) void k_msm_recode(MemberScalars scalars, int m
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
+    if (spread_mod) {
+        uint32_t top = my[7] >> (top_bit & 31u);  // top_bit is in word 7; bit 255 set: not below 2 r, left alone
+        uint32_t k = (top != 0 && (my[7] >> 31) == 0) ? i % spread_mod : 0u;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc += (uint64_t)k * FrCfg::P[j] + my[j];
+            my[j] = (uint32_t)acc;
+            acc >>= 32;
+        }
+        my[8] = (uint32_t)acc;
+    }
     uint32_t carry = 0;
     for (int j = w0 - 1; j >= 0; j--) {
         uint32_t bit = (uint32_t)j * (uint32_t)c;
@@ -1710,8 +1739,9 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         offs.v[b] = members.base_off[b];
         srcs.p[b] = members.scalars[b];
     }
+    uint32_t top_bit = 0, spread_mod = msm_spread(p, &top_bit);
     HALO_LAUNCH(ctx, "k_msm_recode", k_msm_recode, dim3(gridn.x, (unsigned)p.batch), b256, 0, srcs, mont ? 1 : 0, (uint32_t)n, p.c, p.w0, p.w1, p.B,
-                d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
+                spread_mod, top_bit, d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
     // chain bound per lane of the bucket kernel: 64 where the launch is throughput-bound, 16 where it is latency-bound
     uint32_t kmax = msm_kmax(ctx, n);
     bool same_bases = true;  // the small pipeline takes one base offset: members over the same points (the L and R of an IPA round)

@@ -491,7 +491,9 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     // the top window (present in this launch unless a window shard stops short of it)
     uint32_t Wm = Wt / (uint32_t)p.batch;  // windows per member
     uint32_t top_w = p.w1 == p.W ? Wm - 1 : 0xFFFFFFFFu, top_span = p.B, top_rb = p.B / R;
-    {
+    uint32_t spread_bit = 0;
+    if (msm_spread(p, &spread_bit)) top_w = 0xFFFFFFFFu;  // the recode has spread the top digits over the whole window: a window like the others
+    else {
         int top_bits = 256 - p.c * (p.W - 1);  // scalar bits the last window sees (any 256-bit input)
         if (top_bits < p.c) {
             uint32_t safe = 1u << top_bits;                         // magnitudes 1 .. 2^top_bits
