@@ -14,6 +14,7 @@ hiding = "hiding" in sys.argv[3:]
 DEV = "host" not in sys.argv[3:]  # default: the polynomial is resident in device memory (halo_pcdl_open_dev)
 n = 1 << lg; d = n - 1
 ctx = h._lib.Context(urs_n=n)
+if os.environ.get("REDUCE_SPAN"): ctx.set_reduce_span(int(os.environ["REDUCE_SPAN"]))  # development sweep
 _d = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(3, n + 2, _d.data_ptr())
 _co = np.ascontiguousarray(_d.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
