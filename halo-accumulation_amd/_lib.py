@@ -53,6 +53,7 @@ _SIGS = {
     "halo_msm_dev_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "halo_msm_dev_end": (C.c_int, [C.c_void_p, C.c_int, u64p]),
     "halo_msm_points": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
+    "halo_msm_affine": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
     "halo_scalar_dot": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "halo_powers": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
     "halo_poly_eval": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p]),
@@ -80,6 +81,7 @@ _SIGS = {
     "halo_instance_words": (C.c_size_t, [C.c_size_t]),
     "halo_accumulator_words": (C.c_size_t, [C.c_size_t]),
     "halo_pedersen_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
+    "halo_pedersen_commit_affine": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_pcdl_commit": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_pcdl_open": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_pcdl_open_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
@@ -254,6 +256,15 @@ class Context:
         m = min(len(pts_jac), len(scalars))  # msm_unchecked zips to the shorter input
         out = np.zeros(12, dtype=np.uint64)
         check(self.lib.halo_msm_points(self.h, ptr(pts_jac), ptr(scalars), m, ptr(out)))
+        return out
+
+    def msm_affine(self, bases_affine, scalars, mont=True):
+        """point_dot_affine over bases that are not part of the context's key (uploaded for this call)"""
+        bases_affine = np.ascontiguousarray(bases_affine, dtype=np.uint64).reshape(-1, 8)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        m = min(len(bases_affine), len(scalars))  # msm_unchecked zips to the shorter input
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm_affine(self.h, ptr(bases_affine), ptr(scalars), m, int(mont), ptr(out)))
         return out
 
     def scalar_dot(self, xs, ys):

@@ -384,6 +384,32 @@ int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scal
     return HALO_OK;
 }
 
+int halo_msm_affine(halo_ctx *ctx, const uint64_t *bases_affine, const uint64_t *scalars, size_t m, int mont, uint64_t out[12]) {
+    HALO_CTX(ctx);
+    if (!out || (m && (!bases_affine || !scalars))) { set_error("msm_affine: null pointer"); return HALO_E_ARG; }
+    // more generators than the context's workspace holds: consecutive chunks, partial sums added on the host
+    const size_t cap = ctx->n < 64 ? 64 : ctx->n;
+    host::Point acc = host::Point::infinity();
+    for (size_t lo = 0; lo < m || lo == 0; lo += cap) {
+        size_t len = m - lo < cap ? m - lo : cap;
+        // bases: len x 8 words -> native 128-byte entries in d_tmp_b (16 words of room per element); scalars follow in d_tmp_a
+        int rc = upload(ctx, ctx->d_tmp_a, bases_affine + 8 * lo, len * 8);
+        if (rc) return rc;
+        rc = aff_words_to_native(ctx, ctx->d_tmp_a, len, reinterpret_cast<uint32_t *>(ctx->d_tmp_b));
+        if (rc) return rc;
+        HALO_HIP(hipStreamSynchronize(ctx->stream));
+        rc = upload(ctx, ctx->d_tmp_a, scalars + 4 * lo, len * 4);
+        if (rc) return rc;
+        host::Point r;
+        rc = msm_run(ctx, reinterpret_cast<const uint32_t *>(ctx->d_tmp_b), ctx->d_tmp_a, mont != 0, len, &r);
+        if (rc) return rc;
+        acc = acc + r;
+        if (m == 0) break;
+    }
+    acc.store_normalized(out);
+    return HALO_OK;
+}
+
 int halo_scalar_dot(halo_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t m, uint64_t out[4]) {
     HALO_CTX(ctx);
     if (m > (ctx->n < 64 ? 64 : ctx->n)) { set_error("scalar_dot: m exceeds context size"); return HALO_E_ARG; }

@@ -512,6 +512,19 @@ int halo_pedersen_commit(halo_ctx *ctx, const uint64_t *w, size_t n_bases, const
     return HALO_OK;
 }
 
+int halo_pedersen_commit_affine(halo_ctx *ctx, const uint64_t *w, const uint64_t *bases_affine, size_t n_bases, const uint64_t *ms,
+                                size_t n_ms, uint64_t out[12]) {
+    HALO_CTX2(ctx);
+    if (n_bases != n_ms) return fail_assert("Length did not match for pedersen commitment");  // pedersen.rs:7-12
+    uint64_t acc_w[12];
+    int rc = halo_msm_affine(ctx, bases_affine, ms, n_ms, 1, acc_w);  // pedersen.rs:14 over the caller's generators
+    if (rc) return rc;
+    Point acc = Point::load(acc_w);
+    if (w) acc = public_points().S.mul(Fr::load(w)) + acc;  // pedersen.rs:15-17
+    acc.store_normalized(out);
+    return HALO_OK;
+}
+
 int halo_pcdl_commit(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d, const uint64_t *w, uint64_t out[12]) {
     HALO_CTX2(ctx);
     Fr wf = w ? Fr::load(w) : Fr::zero();

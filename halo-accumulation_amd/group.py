@@ -16,8 +16,11 @@ def point_dot(ctx, xs, Gs):
     return ctx.msm_points(Gs, xs)
 
 
-def point_dot_affine(ctx, xs, off=0):
-    """group.rs:24-26 over the resident key GS[off .. off + len(xs))."""
+def point_dot_affine(ctx, xs, Gs=None, off=0):
+    """group.rs:24-26: over the resident key GS[off .. off + len(xs)) (Gs=None), or over the caller's own affine
+    generators Gs (m, 8), uploaded for the call."""
+    if Gs is not None:
+        return ctx.msm_affine(Gs, xs)
     return ctx.msm(xs, off=off)
 
 

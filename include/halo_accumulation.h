@@ -92,8 +92,15 @@ int halo_msm_dev_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, cons
                              int scalars_are_mont, int part, int parts);
 int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out_jac);
 /* point_dot (group.rs:18-21): arbitrary Jacobian points (m x 12 limbs); they are brought to
- * affine with one batched inversion instead of the reference's m separate ones. */
+ * affine on the device (one Montgomery batch inversion per 256-point block; the reference runs m separate ones). */
 int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out_jac[12]);
+/* point_dot_affine (group.rs:24-26) for bases that are NOT a stretch of the context's key: pedersen::commit
+ * (pedersen.rs:6-20) is public API over any `&[PallasAffine]`, and the reference's own test_homomorphism_property
+ * (pedersen.rs:30-63) is free to pass other generators.  bases_affine = m x 8 limbs, uploaded for this call
+ * ((0,0) = infinity); more generators than the context holds points run as consecutive chunks.  The general
+ * (table-free) Pippenger pipeline runs. */
+int halo_msm_affine(halo_ctx *ctx, const uint64_t *bases_affine, const uint64_t *scalars, size_t m, int scalars_are_mont,
+                    uint64_t out_jac[12]);
 /* scalar_dot (group.rs:13-15) */
 int halo_scalar_dot(halo_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t m, uint64_t out[4]);
 /* construct_powers (group.rs:29-37): [1, z, ..., z^(n-1)] */
@@ -167,6 +174,10 @@ size_t halo_accumulator_words(size_t lg_n);
 /* pedersen::commit (pedersen.rs:6-20) over GS[0..n_bases) */
 int halo_pedersen_commit(halo_ctx *ctx, const uint64_t *w /*nullable*/, size_t n_bases, const uint64_t *ms, size_t n_ms,
                          uint64_t out[12]);
+/* pedersen::commit (pedersen.rs:6-20) over generators the caller passes (n_bases x 8 limbs; not the context's key):
+ * the signature takes any `&[PallasAffine]` (pedersen.rs:6), this is that case; halo_msm_affine underneath */
+int halo_pedersen_commit_affine(halo_ctx *ctx, const uint64_t *w /*nullable*/, const uint64_t *bases_affine, size_t n_bases,
+                                const uint64_t *ms, size_t n_ms, uint64_t out[12]);
 /* pcdl::commit (pcdl.rs:99-110) */
 int halo_pcdl_commit(halo_ctx *ctx, const uint64_t *coeffs, size_t len, size_t d, const uint64_t *w /*nullable*/, uint64_t out[12]);
 /* pcdl::open (pcdl.rs:120-242) */

@@ -1,6 +1,6 @@
 //! `code/src/ffi.rs` -- binding of libhalo_hip.so (include/halo_accumulation.h) for rasmus-kirk/halo-accumulation.
 //!
-//! Drop this file into `code/src/`, add `mod ffi;` to `lib.rs` and apply `group_rs.patch` / `pcdl_rs.patch`.
+//! Drop this file into `code/src/` and apply `lib_rs.patch` (`mod ffi;`), `group_rs.patch` and `pcdl_rs.patch`.
 //! `build.rs` next to it tells cargo where the library is.  NOT COMPILED in the build image of this repository
 //! (no Rust toolchain there): the C side is exercised through the identical C ABI by `integration/harness.c`
 //! and by the ctypes binding of the parity tests.
@@ -11,8 +11,14 @@ use std::sync::OnceLock;
 
 use ark_ff::{BigInt, PrimeField};
 
-use crate::consts::GS;
+use crate::consts::{GS, N};
 use crate::group::{PallasAffine, PallasPoint, PallasScalar};
+
+/// The commitment key at ONE address.  `consts::GS` is a `const`: every `&GS[a..b]` in the crate borrows a fresh
+/// (promoted or stack) copy, so a slice of it cannot be recognised by address.  `pcdl_rs.patch` makes `pcdl.rs` read the
+/// key through this static (`use crate::ffi::KEY as GS`); `point_dot_affine` below recognises slices of it and sends
+/// everything else -- any other `&[PallasAffine]` a caller of `pedersen::commit` may pass -- through `halo_msm_affine`.
+pub static KEY: [PallasAffine; N] = GS;
 
 #[repr(C)] pub struct HaloCtx { _p: [u8; 0] }
 #[repr(C)] pub struct HaloIpa { _p: [u8; 0] }
@@ -30,6 +36,7 @@ extern "C" {
     pub fn halo_ctx_destroy(ctx: *mut HaloCtx);
     pub fn halo_msm(ctx: *mut HaloCtx, off: usize, n: usize, scalars: *const u64, mont: c_int, out_jac: *mut u64) -> c_int;
     pub fn halo_msm_points(ctx: *mut HaloCtx, pts_jac: *const u64, scalars: *const u64, m: usize, out_jac: *mut u64) -> c_int;
+    pub fn halo_msm_affine(ctx: *mut HaloCtx, bases_affine: *const u64, scalars: *const u64, m: usize, mont: c_int, out_jac: *mut u64) -> c_int;
     pub fn halo_scalar_dot(ctx: *mut HaloCtx, xs: *const u64, ys: *const u64, m: usize, out: *mut u64) -> c_int;
     pub fn halo_powers(ctx: *mut HaloCtx, z: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn halo_poly_eval(ctx: *mut HaloCtx, coeffs: *const u64, len: usize, z: *const u64, out: *mut u64) -> c_int;
@@ -90,18 +97,27 @@ pub fn ctx() -> *mut HaloCtx {
     static CTX: OnceLock<usize> = OnceLock::new();
     *CTX.get_or_init(|| {
         let mut c = std::ptr::null_mut();
-        let limbs = aff_limbs(&GS);
-        ck(unsafe { halo_ctx_create(0, limbs.as_ptr(), GS.len(), &mut c) });
+        let limbs = aff_limbs(&KEY);
+        ck(unsafe { halo_ctx_create(0, limbs.as_ptr(), KEY.len(), &mut c) });
         c as usize
     }) as *mut HaloCtx
 }
 
 // ---- the group.rs function set (group.rs:13-37) ------------------------------------------------------------------
-/// `point_dot_affine(xs, &GS[off..off + n])`: every call site passes a prefix of the constant key (pcdl.rs:109,338)
-pub fn msm_key_prefix(xs: &[PallasScalar], off: usize, n: usize) -> PallasPoint {
-    let n = n.min(xs.len()); // msm_unchecked zips to the shorter input
+/// `point_dot_affine` (group.rs:24-26).  A slice that lies inside the static `KEY` IS that stretch of the key (the static is
+/// immutable), so it is named by (offset, length) and runs over the resident bases -- fixed-base tables and all.  Any
+/// other slice is sent along with the call.  Both are sound for every `Gs`; only the speed differs.
+pub fn point_dot_affine(xs: &[PallasScalar], gs: &[PallasAffine]) -> PallasPoint {
+    let n = gs.len().min(xs.len()); // msm_unchecked zips to the shorter input
+    let sz = std::mem::size_of::<PallasAffine>();
+    let (lo, hi) = (KEY.as_ptr() as usize, KEY.as_ptr() as usize + KEY.len() * sz);
+    let p = gs.as_ptr() as usize;
     let mut out = [0u64; 12];
-    ck(unsafe { halo_msm(ctx(), off, n, fr_limbs(&xs[..n]).as_ptr(), 1, out.as_mut_ptr()) });
+    if p >= lo && p + gs.len() * sz <= hi && (p - lo) % sz == 0 {
+        ck(unsafe { halo_msm(ctx(), (p - lo) / sz, n, fr_limbs(&xs[..n]).as_ptr(), 1, out.as_mut_ptr()) });
+    } else {
+        ck(unsafe { halo_msm_affine(ctx(), aff_limbs(&gs[..n]).as_ptr(), fr_limbs(&xs[..n]).as_ptr(), n, 1, out.as_mut_ptr()) });
+    }
     point_from(out)
 }
 pub fn point_dot(xs: &[PallasScalar], gs: &[PallasPoint]) -> PallasPoint {

@@ -78,6 +78,17 @@ int main(int argc, char **argv) {
     CK(halo_proof_encode(pb, bytes, cap, &blen));
     CK(halo_proof_decode(bytes, blen, pc, words, &lg_back));
     int wire = blen == cap && lg_back == lg && memcmp(pb, pc, words * 8) == 0;
+    /* the shim's point_dot_affine (ffi.rs) has two routes: a slice of the static key by (offset, length) through halo_msm,
+     * anything else with its generators through halo_msm_affine.  Same generators -> same point, whichever route. */
+    size_t mk = n < 512 ? n : 512, koff = n - mk;
+    uint64_t *gs = malloc(mk * 64), P1[12], P2[12];
+    CK(halo_ctx_read_bases(ctx, koff, mk, gs));
+    CK(halo_msm(ctx, koff, mk, coeffs, 1, P1));
+    CK(halo_msm_affine(ctx, gs, coeffs, mk, 1, P2));
+    int routes = memcmp(P1, P2, 96) == 0;
+    free(gs);
+    printf("point_dot_affine routes agree: %s\n", routes ? "yes" : "NO");
+    same = same && routes;
     printf("lg_n=%zu  shim loop == halo_pcdl_open: %s   check(a)=%d check(b)=%d   wire round trip: %s (%zu bytes)\n", lg, same ? "yes" : "NO", ok_a,
            ok_b, wire ? "yes" : "NO", blen);
     halo_ctx_destroy(ctx);

@@ -159,6 +159,38 @@ def test_pedersen_homomorphism(hal, ctx):
         pedersen.commit(ctx, None, l, m1[:-1])
 
 
+@pytest.mark.parametrize("l", [1, 3, 64, 1000, 4096])
+def test_pedersen_commit_over_callers_generators(hal, ctx, pp, l):
+    """pedersen::commit takes ANY `&[PallasAffine]` (pedersen.rs:6): generators that are not a stretch of the context's key
+    go through halo_msm_affine (bases uploaded per call).  Reversed key, a key derived from other URS indices, an
+    infinity among the bases -- against the oracle's arkworks-style Pippenger over the same arrays."""
+    from halo_accumulation_amd import group, pedersen
+    other = hal._lib.Context(urs_n=l, first_index=100000)
+    try:
+        foreign = other.read_bases()
+    finally:
+        other.close()
+    rev = ctx.read_bases()[::-1][:l].copy()
+    holes = foreign.copy()
+    holes[l // 2] = 0  # (0, 0) = point at infinity
+    ms, s = orc.rng_scalars(900 + l, l)
+    w, _ = orc.rng_scalars(s, 1)
+    for Gs in (foreign, rev, holes):
+        assert group.point_dot_affine(ctx, ms, Gs=Gs).tolist() == orc.msm_affine(Gs, ms).tolist()
+        for ww in (None, w[0]):
+            want = orc.z(12)
+            assert orc.lib().orc_pedersen_commit(orc.C.byref(pp), None if ww is None else orc.ptr(ww), orc.ptr(Gs), orc.C.c_size_t(l), orc.ptr(ms),
+                                                 orc.C.c_size_t(l), orc.ptr(want)) == 0
+            assert canon(pedersen.commit(ctx, ww, Gs, ms)) == canon(want)
+    # homomorphism over the caller's generators (pedersen.rs:30-63 with Gs that are not consts::GS)
+    m2, s = orc.rng_scalars(s, l)
+    o = orc.z(12)
+    orc.lib().orc_point_add(orc.ptr(pedersen.commit(ctx, None, foreign, ms)), orc.ptr(pedersen.commit(ctx, None, foreign, m2)), orc.ptr(o))
+    assert pedersen.commit(ctx, None, foreign, ctx.field_op(1, 1, ms, m2)).tolist() == o.tolist()
+    with pytest.raises(AssertionError):
+        pedersen.commit(ctx, None, foreign, ms[:-1]) if l > 1 else pedersen.commit(ctx, None, foreign, np.zeros((2, 4), dtype=np.uint64))
+
+
 @pytest.mark.parametrize("n,hiding", [(4, False), (4, True), (16, True), (512, False), (512, True), (4096, True)])
 def test_open_check_matches_oracle(hal, ctx, pp, n, hiding, ipa_mode):
     """pcdl.rs:441-483 completeness, and proof blobs identical to the CPU restatement's."""
