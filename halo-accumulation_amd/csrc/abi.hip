@@ -200,7 +200,8 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
         st->s_host.assign(1, host::Fr::one());
     } while (0);
     if (rc) { halo_ipa_destroy(st); return rc; }
-    ctx->worker.set_hot(true);
+    ctx->worker.add_hot(1);
+    st->counted_hot = true;
     *out = st;
     return HALO_OK;
 }
@@ -789,7 +790,7 @@ void halo_ipa_destroy(halo_ipa *st) {
         (void)hipSetDevice(ctx->device);
         for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->streams[k]);  // folds, the second MSM, the dot products
     }
-    if (ctx) ctx->worker.set_hot(false);
+    if (ctx && st->counted_hot) ctx->worker.add_hot(-1);
     if (st->borrowed && ctx) {
         ctx->ipa_bufs.d_pbar = st->d_pbar;  // lazily allocated by the hiding branch of a sharded open: kept with the rest
         ctx->ipa_bufs.in_use = false;
@@ -956,6 +957,11 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode) {
 }
 int halo_set_table_mode(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("table mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
+    if (mode == 0 && ctx->d_table) {  // "no table memory": a table already built is released, not just left unused
+        HALO_CTX(ctx);
+        int rc = table_release(ctx);
+        if (rc) return rc;
+    }
     ctx->table_mode = mode;
     return HALO_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -137,8 +138,10 @@ constexpr int HALO_SLOTS = 4;
 namespace halo {
 // One helper thread per context for pure host arithmetic that would otherwise serialise on the caller's thread
 // (the window combine of the second MSM of an IPA round while the caller combines the first).  It never touches
-// HIP.  While `hot` (an IPA state is alive) it polls for work instead of sleeping: a round arrives every few
-// hundred microseconds and a condition-variable wake-up would cost a good part of what the overlap saves.
+// HIP.  While an IPA state of the context is alive (`hot` counts them) a round arrives every few hundred
+// microseconds and a condition-variable wake-up would cost a good part of what the overlap saves, so after a job
+// the thread polls for the next one -- but only for SPIN_US: an idle state (a caller thinking between rounds, a long
+// sharded open waiting on a collective) does not hold a core; the thread falls back to the condition variable.
 class HostWorker {
    public:
     ~HostWorker() { stop(); }
@@ -153,9 +156,10 @@ class HostWorker {
         if (!thread_.joinable()) return;
         while (!done_.load(std::memory_order_acquire)) std::this_thread::yield();
     }
-    void set_hot(bool hot) {
-        hot_.store(hot, std::memory_order_relaxed);
-        if (hot) { start(); cv_.notify_one(); }
+    // one call per IPA state created (+1) / destroyed (-1)
+    void add_hot(int delta) {
+        int now = hot_.fetch_add(delta, std::memory_order_relaxed) + delta;
+        if (delta > 0 && now > 0) start();
     }
     void stop() {
         if (!thread_.joinable()) return;
@@ -165,30 +169,38 @@ class HostWorker {
     }
 
    private:
+    static constexpr long SPIN_US = 600;
     void start() {
         if (thread_.joinable()) return;
         done_.store(true);
         thread_ = std::thread([this] { loop(); });
     }
     void loop() {
+        auto last = std::chrono::steady_clock::now();
         for (;;) {
             if (!pending_.load(std::memory_order_acquire)) {
                 if (quit_.load()) return;
-                if (hot_.load(std::memory_order_relaxed)) { std::this_thread::yield(); continue; }
+                if (hot_.load(std::memory_order_relaxed) > 0 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - last).count() < SPIN_US) {
+                    std::this_thread::yield();
+                    continue;
+                }
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return pending_.load() || quit_.load() || hot_.load(); });
+                cv_.wait(lk, [this] { return pending_.load() || quit_.load(); });
                 continue;
             }
             pending_.store(false, std::memory_order_relaxed);
             job_();
             done_.store(true, std::memory_order_release);
+            last = std::chrono::steady_clock::now();
         }
     }
     std::thread thread_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::function<void()> job_;
-    std::atomic<bool> pending_{false}, done_{true}, quit_{false}, hot_{false};
+    std::atomic<bool> pending_{false}, done_{true}, quit_{false};
+    std::atomic<int> hot_{0};
 };
 }  // namespace halo
 
@@ -256,6 +268,7 @@ struct halo_ipa {
     uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
     uint64_t *d_pbar = nullptr;  // n x 4: this shard of p_bar (hiding branch of the sharded open)
     bool pbar_valid = false;     // halo_ipa_hiding_partial has filled d_pbar for this state
+    bool counted_hot = false;    // this state is counted in ctx->worker's hot count (undone by halo_ipa_destroy)
     bool borrowed = false;       // buffers belong to ctx->ipa_bufs (returned, not freed, by halo_ipa_destroy)
 };
 
@@ -266,6 +279,7 @@ namespace halo {
 inline void alloc_epoch_bump(halo_ctx *ctx) { ctx->alloc_epoch++; }
 int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);
 void msm_workspace_free(halo_ctx *ctx);
+int table_release(halo_ctx *ctx);  // frees the context's fixed-base table (every slot idle)
 // asynchronous halves of msm_run on workspace/stream `slot`
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n);
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out);

@@ -1592,15 +1592,46 @@ static int table_build(halo_ctx *ctx) {
     size_t n = ctx->n;
     TblPlan tp = table_plan(n);
     alloc_epoch_bump(ctx);
-    if (hipMalloc(&ctx->d_table, (size_t)tp.W * n * 128) != hipSuccess) { ctx->d_table = nullptr; set_error("msm: no memory for the fixed-base table"); return HALO_E_DEVICE; }
-    if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)ctx->d_table, (size_t)tp.W * n * 128);
-    HALO_HIP(hipMemcpyAsync(ctx->d_table, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int w = 1; w < tp.W; ++w)
-        HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->d_table + (size_t)(w - 1) * n * AFF_STRIDE,
-                    (uint32_t)n, tp.c, ctx->d_table + (size_t)w * n * AFF_STRIDE);
-    HALO_HIP(hipGetLastError());
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    // built into a local pointer and published (d_table + tbl together) only after the last step has succeeded: a
+    // half-built table is never visible to table_eligible / tmsm_enqueue_piece
+    uint32_t *tbl = nullptr;
+    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tbl, (size_t)tp.W * n * 128);  // (test hook: the failure path)
+    if (e == hipSuccess) {
+        if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)tbl, (size_t)tp.W * n * 128);
+        e = hipMemcpyAsync(tbl, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream);
+        for (int w = 1; w < tp.W && e == hipSuccess; ++w) {
+            HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tbl + (size_t)(w - 1) * n * AFF_STRIDE, (uint32_t)n,
+                        tp.c, tbl + (size_t)w * n * AFF_STRIDE);
+            e = hipGetLastError();
+        }
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e != hipSuccess) {
+        // No table, no problem: the general pipeline needs no table memory and gives the same point.  The context stops
+        // trying (every later eligible MSM would fail the same way) and says so once.
+        (void)hipGetLastError();
+        if (tbl) (void)hipFree(tbl);
+        ctx->table_mode = 0;
+        fprintf(stderr, "[halo] fixed-base table of %zu bytes not built (%s): this context continues without tables\n", (size_t)tp.W * n * 128,
+                hipGetErrorString(e));
+        return HALO_OK;
+    }
     ctx->tbl = tp;
+    ctx->d_table = tbl;
+    return HALO_OK;
+}
+// halo_set_table_mode(ctx, 0): the table's memory goes back to the device (its launches have drained: every slot is idle)
+int table_release(halo_ctx *ctx) {
+    if (!ctx->d_table) return HALO_OK;
+    for (int k = 0; k < HALO_SLOTS; ++k) {
+        if (ctx->wss[k].in_flight) { set_error("table mode: an MSM is in flight on this context"); return HALO_E_ARG; }
+        HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
+    }
+    alloc_epoch_bump(ctx);  // cached launch graphs name the table
+    (void)hipFree(ctx->d_table);
+    ctx->d_table = nullptr;
+    ctx->tbl = TblPlan{};
     return HALO_OK;
 }
 // can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key -- of at least 2^20
@@ -1887,11 +1918,6 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count) {
     MsmPlan p = ws.plan;
     for (int b = 0; b < count; ++b) out[b] = host::Point::infinity();
     if (p.W == 0) return;
-    if (p.table_vw > 0) {
-        // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ]
-        for (int b = 0; b < count; ++b) msm_combine_member(ctx, slot, b, &out[b]);
-        return;
-    }
     for (int b = 0; b < count; ++b) msm_combine_member(ctx, slot, b, &out[b]);
 }
 int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count) {

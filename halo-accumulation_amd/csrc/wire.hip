@@ -180,6 +180,11 @@ size_t read_instance(Reader &r, uint64_t *q, size_t cap_words) {
     return lg;
 }
 
+// a blob's own words say how long it is: a corrupted or foreign blob must not send the encoder out of bounds
+// (the decoders cap lg at 40 as well)
+bool blob_header_ok(const uint64_t *pf) { return pf[0] <= 1 && pf[1] <= 40; }
+int bad_blob() { set_error("encode: not an EvalProof blob (hiding flag > 1 or lg > 40)"); return HALO_E_ARG; }
+
 int finish_write(const Writer &w, size_t *len) {
     if (!w.ok) { set_error("encode: output buffer too small"); return HALO_E_ARG; }
     *len = w.pos;
@@ -201,6 +206,7 @@ size_t halo_accumulator_encoded_size(size_t lg_n) { return halo_instance_encoded
 
 int halo_proof_encode(const uint64_t *proof, uint8_t *out, size_t cap, size_t *len) {
     if (!proof || !out || !len) { set_error("encode: null pointer"); return HALO_E_ARG; }
+    if (!blob_header_ok(proof)) return bad_blob();
     Writer w{out, cap};
     write_proof(w, proof);
     return finish_write(w, len);
@@ -215,6 +221,7 @@ int halo_proof_decode(const uint8_t *in, size_t len, uint64_t *proof_out, size_t
 }
 int halo_instance_encode(const uint64_t *inst, uint8_t *out, size_t cap, size_t *len) {
     if (!inst || !out || !len) { set_error("encode: null pointer"); return HALO_E_ARG; }
+    if (!blob_header_ok(inst + 21)) return bad_blob();
     Writer w{out, cap};
     write_instance(w, inst);
     return finish_write(w, len);
@@ -230,6 +237,7 @@ int halo_instance_decode(const uint8_t *in, size_t len, uint64_t *inst_out, size
 // Accumulator = Instance fields | pi_V { h: DensePolynomial (<= 2 coefficients, trailing zeros stripped), U, w }
 int halo_accumulator_encode(const uint64_t *acc, uint8_t *out, size_t cap, size_t *len) {
     if (!acc || !out || !len) { set_error("encode: null pointer"); return HALO_E_ARG; }
+    if (!blob_header_ok(acc + 21)) return bad_blob();
     Writer w{out, cap};
     write_instance(w, acc);
     size_t lg = (size_t)acc[22];

@@ -418,6 +418,38 @@ def test_msm_table_pipeline_equals_general(hal):
         c.close()
 
 
+def test_table_memory_failure_and_release(hal, monkeypatch):
+    """(a) a context whose fixed-base table cannot be built (no memory) carries on through the general pipeline --
+    same point, no error, no retry per MSM; (b) halo_set_table_mode(ctx, 0) gives a table that was already built back to the
+    device (the header says "no table memory")."""
+    import torch
+    n = 1 << 17
+    sc, _ = orc.rng_scalars(0x7AB1E, n)
+    good = hal.Context(urs_n=n)
+    try:
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        want = good.msm(sc)                      # builds the c = 17 table: 15 x 128 B per point
+        assert want.tolist() == orc.msm_affine(good.read_bases(), sc).tolist()
+        free1 = torch.cuda.mem_get_info()[0]
+        table_bytes = 15 * 128 * n
+        assert free0 - free1 >= table_bytes      # (the first MSM may also allocate slot buffers)
+        good.set_table_mode(0)
+        assert torch.cuda.mem_get_info()[0] - free1 >= table_bytes * 9 // 10, "set_table_mode(0) must release the table"
+        assert good.msm(sc).tolist() == want.tolist()
+        good.set_table_mode(-1)                  # and it comes back on demand
+        assert good.msm(sc).tolist() == want.tolist()
+    finally:
+        good.close()
+    monkeypatch.setenv("HALO_TEST_TABLE_FAIL", "1")   # the allocation of the table fails
+    bad = hal.Context(urs_n=n)
+    try:
+        for _ in range(3):
+            assert bad.msm(sc).tolist() == want.tolist()
+    finally:
+        bad.close()
+
+
 @pytest.mark.parametrize("n", [1 << 20, 1 << 17, (1 << 18) + 4096, 1 << 19, (1 << 20) + (1 << 18) + 4100])
 def test_msm_table_top_window_edges(hal, n):
     """The table pipeline's plans: keys of >= 2^20 points recode s + (i mod 31) r when the scalar's top window (bits 240..)

@@ -129,3 +129,23 @@ def test_decode_rejects_malformed_input(hal, pp):
         got = hal.proof_decode(bytes(b))
         xy = orc.point_canonical(got[2:14])
         assert xy[0] == pm.P - 1 and (xy[1] > pm.P - xy[1]) == (flag == 0x80) and xy[1] in (2, pm.P - 2)
+
+
+def test_encode_rejects_blobs_with_a_corrupt_header(hal, pp):
+    """The encoders take lg and the hiding flag from the blob itself: a corrupted or foreign blob must be refused, not
+    read out of bounds (the decoders cap lg at 40 the same way)."""
+    coeffs, s = orc.rng_scalars(3, 8)
+    zw, _ = orc.rng_scalars(s, 2)
+    Cm = orc.pcdl_commit(pp, coeffs, 7, zw[1])
+    pf, _ = orc.pcdl_open(pp, 5, coeffs, Cm, 7, zw[0], zw[1])
+    lib = hal.load()
+    buf = hal.C.create_string_buffer(1 << 16)
+    n = hal.C.c_size_t()
+    for word, value in ((1, 41), (1, 2**40), (0, 2)):
+        bad = pf.copy()
+        bad[word] = value
+        assert lib.halo_proof_encode(hal.ptr(bad), buf, len(buf), hal.C.byref(n)) == hal.HALO_E_ARG
+        inst = np.concatenate([np.zeros(21, dtype=np.uint64), bad])
+        assert lib.halo_instance_encode(hal.ptr(inst), buf, len(buf), hal.C.byref(n)) == hal.HALO_E_ARG
+        acc = np.concatenate([inst, np.zeros(24, dtype=np.uint64)])
+        assert lib.halo_accumulator_encode(hal.ptr(acc), buf, len(buf), hal.C.byref(n)) == hal.HALO_E_ARG
