@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
+    ap.add_argument("--fr-reps", type=int, default=20, help="back-to-back launches of each bandwidth-side Fr kernel at N=1 (0 = skip)")
     ap.add_argument("--asdl-steps", type=int, default=8, help="ASDL chain steps (random_instance + prover + verifier, then one decider) at N=1 (0 = skip)")
     args = ap.parse_args()
 
@@ -359,6 +360,25 @@ def main():
                                                   "coefficients copied from pageable host memory per open (halo_pcdl_open); median of %d samples "
                                                   "(two sets of %d, before and after the host-path runs, pooled)" % (len(pooled), args.open_steps),
                                           "samples_ms": [round(t * 1e3, 3) for t in ts_a + ts_b]}
+        if args.fr_reps > 0:
+            # The bandwidth-side Fr kernels, each alone: `fr_reps` back-to-back launches through the library's
+            # measurement hook, HIP events around every launch (these include ~2-3 us of dispatch per launch; the rocprofv3
+            # durations of the same program, tools/fr_kernels.py, are in profiles/).  Algorithmic bytes per kernel as listed.
+            FR = [(0, "k_powers", 32 * n, "valu"), (1, "k_poly_eval_partial", 32 * n, "valu"), (2, "k_dot2_partial", 64 * n, "hbm"),
+                  (4, "k_h_coeffs", 32 * n, "valu"), (5, "k_fold_scalars", 192 * (n // 2), "hbm"), (6, "k_axpy", 96 * n, "hbm")]
+            hk = {}
+            ctx.bench_fr_kernel(5, n, 3)
+            for which, name, alg, bound in FR:
+                ctx.prof_enable(1); ctx.prof_reset()
+                ctx.bench_fr_kernel(which, n, args.fr_reps)
+                ms, cnt = ctx.prof()[name]
+                ctx.prof_enable(0)
+                hk[name] = {"ms": ms / cnt, "algorithmic_bytes": alg, "achieved": alg / (ms / cnt) / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "frac": alg / (ms / cnt) / 1e6 / HBM_PEAK_GBS, "bound": bound}
+            result["hbm_kernels"] = {"n": n, "launches_each": args.fr_reps, "kernels": hk,
+                                     "note": "bound = valu: one 255-bit modular product per 32 bytes moved; the bare product loop runs at 8.2 us per "
+                                             "2^20 products on this chip (tools/fr29_bench.hip), i.e. 4.1 TB/s-equivalent before any load, store or "
+                                             "conversion -- see DESIGN.md 4.4"}
         if args.asdl_steps > 0:
             # BASELINE configs[3], the shape of benches/acc.rs:64-98 on a short chain: K x (random_instance + prover), K x verifier,
             # one decider (tests/test_gpu_pcdl_acc.py runs the full 64-step chain)

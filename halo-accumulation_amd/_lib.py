@@ -107,6 +107,7 @@ _SIGS = {
     "halo_prof_reset": (C.c_int, [C.c_void_p]),
     "halo_prof_count": (C.c_int, [C.c_void_p]),
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "halo_bench_fr_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_msm_dev_begin_part": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "halo_msm_dev_batch_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
@@ -329,6 +330,10 @@ class Context:
             check(self.lib.halo_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def bench_fr_kernel(self, which: int, n: int, reps: int):
+        """reps back-to-back launches of one Fr kernel (0 powers, 1 poly_eval, 2 dot, 3 dot2 of a round, 4 h_coeffs, 5 fold_scalars, 6 axpy)"""
+        check(self.lib.halo_bench_fr_kernel(self.h, which, n, reps))
 
     def rng_scalars_dev(self, state: int, n: int, dptr: int) -> int:
         """Fill device memory with n scalars of the SplitMix64 stream; returns the advanced state."""

@@ -73,6 +73,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipMalloc(&ctx->d_tmp_b, tn * 16 * 8));
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
+    HALO_HIP(hipHostMalloc(&ctx->h_wintab, 8192));
     if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;  // HALO_GRAPHS=0: never replay launch graphs
     return msm_workspace_alloc(ctx, n, 0);
 }
@@ -275,6 +276,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_poly2);
     (void)hipFree(ctx->d_verify);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_wintab) (void)hipHostFree(ctx->h_wintab);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
@@ -830,6 +832,10 @@ int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, lon
     if (total_ms) *total_ms = ctx->prof.entries[i].total_ms;
     if (launches) *launches = ctx->prof.entries[i].launches;
     return HALO_OK;
+}
+int halo_bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps) {
+    HALO_CTX(ctx);
+    return bench_fr_kernel(ctx, which, n, reps);
 }
 // ---- host steps of a sharded pcdl::open (halo-accumulation_amd/sharded.py) ---------------------
 int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, size_t P, uint64_t v_out[4], uint64_t xi0[4],

@@ -239,6 +239,7 @@ struct halo_ctx {
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
+    uint64_t *h_wintab = nullptr;  // pinned staging of a window table of powers (ipa.hip upload_window_table), 8 KiB
     uint64_t *d_verify = nullptr;  // staging of the batched verifier (points, scalars, challenges, results), grown on demand
     size_t verify_words = 0;
     // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover
@@ -330,6 +331,7 @@ int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, 
 int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a);
 int pbar_stream_dev(halo_ctx *ctx, uint64_t state0, size_t deg, const host::Fr &z, uint64_t stride, uint64_t offset, size_t n_local,
                     uint64_t *d_out);
+int bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps);
 int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_L, uint64_t *d_R);
 int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out);
 

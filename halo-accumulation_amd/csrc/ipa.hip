@@ -6,9 +6,30 @@
 // The point fold uses ONE scalar for the whole launch, so every lane runs the same
 // double-and-add schedule with no divergence.
 #include "curve_quad.hpp"
+#include "fr29.hpp"
 #include "internal.hpp"
 
 namespace halo {
+
+// An Fr multiplier in N-form (fr29.hpp: k 2^261 mod r = the Montgomery limbs of 32 k), 9 x 29-bit limbs by value
+struct FsArg { uint32_t v[9]; };
+static FsArg to_nform(const host::Fr &k) {
+    host::Fr t = k * host::Fr::from_u64(32);
+    FsArg a;
+    for (int i = 0; i < 9; ++i) {
+        int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t lo = t.l[w] >> sh;
+        if (sh > 35 && w + 1 < 4) lo |= t.l[w + 1] << (64 - sh);
+        a.v[i] = (uint32_t)(i < 8 ? (lo & ((1u << 29) - 1)) : lo);
+    }
+    return a;
+}
+HALO_DEV Fs<1> from_nform(const FsArg &a) {
+    Fs<1> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i];
+    return r;
+}
 
 struct FeArg { uint32_t v[8]; };  // by-value kernel argument (SGPRs)
 static FeArg to_arg(const host::Fr &f) {
@@ -237,15 +258,15 @@ __global__ __launch_bounds__(256, 2) void k_fold_points4_quad(const uint32_t *G,
 }
 
 // ------------------------------------------------------------------ K4: c' = c_l + xi^-1 c_r ; z' = z_l + xi z_r
-__global__ __launch_bounds__(256) void k_fold_scalars(uint64_t *__restrict__ c, uint64_t *__restrict__ z, uint32_t m, FeArg xi,
-                                                      FeArg xi_inv) {
+// 192 bytes moved and two products per element: HBM-bound with the 29-bit product (fr29.hpp)
+__global__ __launch_bounds__(256) void k_fold_scalars(uint64_t *__restrict__ c, uint64_t *__restrict__ z, uint32_t m, FsArg xi,
+                                                      FsArg xi_inv) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
-    Fe x = from_arg(xi), xinv = from_arg(xi_inv);
     Fe cl = fe_load(c + 4 * (size_t)j), cr = fe_load(c + 4 * (size_t)(j + m));
     Fe zl = fe_load(z + 4 * (size_t)j), zr = fe_load(z + 4 * (size_t)(j + m));
-    fe_store(c + 4 * (size_t)j, fe_add<FrCfg>(cl, fe_mul<FrCfg>(cr, xinv)));
-    fe_store(z + 4 * (size_t)j, fe_add<FrCfg>(zl, fe_mul<FrCfg>(zr, x)));
+    fs_store(c + 4 * (size_t)j, fs_add(fs_from_fe(cl), fs_mul(fs_from_fe(cr), from_nform(xi_inv))));
+    fs_store(z + 4 * (size_t)j, fs_add(fs_from_fe(zl), fs_mul(fs_from_fe(zr), from_nform(xi))));
 }
 
 // ------------------------------------------------------------------ block-wide Fr sum
@@ -265,91 +286,168 @@ HALO_DEV Fe block_sum_fr(Fe v, Fe *lds /* >= 4 entries */) {
 }
 
 // ------------------------------------------------------------------ K5: two dot products per launch
+// A lane takes two elements of each pair of vectors per trip -- x_i y_i + x_j y_j share one reduction -- and the next
+// trip's operands are requested before the current products run.  The products of two A-form values carry 1/32
+// (fr29.hpp): the partial sums stay in that skewed form and k_sum_partials multiplies the total by 32 once.
+// The grid is kept small (two waves per SIMD): with one trip per lane the block-wide sum cost as many instructions as the
+// products themselves.
+struct DotOps { Fe x, y, x2, y2; };
+HALO_DEV DotOps dot_load(const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, uint32_t i, uint32_t i2, uint32_t m) {
+    DotOps o;
+    uint32_t j = i2 < m ? i2 : i;  // (past the end: the slot re-reads element i and is zeroed)
+    o.x = fe_load(xs + 4 * (size_t)i); o.y = fe_load(ys + 4 * (size_t)i);
+    o.x2 = fe_load(xs + 4 * (size_t)j); o.y2 = fe_load(ys + 4 * (size_t)j);
+    if (i2 >= m) o.x2 = fe_zero();
+    return o;
+}
+HALO_DEV Fs<2> dot_step(const Fs<2> &acc, const DotOps &o) {
+    return fs_tighten(fs_add(acc, fs_mul_add_mul(fs_from_fe(o.x), fs_from_fe(o.y), fs_from_fe(o.x2), fs_from_fe(o.y2))));
+}
+template <bool HAS1>
 __global__ __launch_bounds__(256) void k_dot2_partial(const uint64_t *__restrict__ xs0, const uint64_t *__restrict__ ys0,
                                                       const uint64_t *__restrict__ xs1, const uint64_t *__restrict__ ys1, uint32_t m,
                                                       uint64_t *__restrict__ partial) {
     __shared__ Fe lds[8];
-    Fe a0 = fe_zero(), a1 = fe_zero();
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
-        if (xs0) a0 = fe_add<FrCfg>(a0, fe_mul<FrCfg>(fe_load(xs0 + 4 * (size_t)i), fe_load(ys0 + 4 * (size_t)i)));
-        if (xs1) a1 = fe_add<FrCfg>(a1, fe_mul<FrCfg>(fe_load(xs1 + 4 * (size_t)i), fe_load(ys1 + 4 * (size_t)i)));
+    Fs<2> a0 = fs_zero<2>(), a1 = fs_zero<2>();
+    const uint32_t stride = gridDim.x * 256;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        DotOps n0 = dot_load(xs0, ys0, i, i + stride, m), n1 = n0;
+        if (HAS1) n1 = dot_load(xs1, ys1, i, i + stride, m);
+        for (; i < m; i += 2 * stride) {
+            DotOps c0 = n0, c1 = n1;
+            uint32_t nx = i + 2 * stride;
+            if (nx < m) {
+                n0 = dot_load(xs0, ys0, nx, nx + stride, m);
+                if (HAS1) n1 = dot_load(xs1, ys1, nx, nx + stride, m);
+            }
+            a0 = dot_step(a0, c0);
+            if (HAS1) a1 = dot_step(a1, c1);
+        }
     }
-    Fe s0 = block_sum_fr(a0, lds);
-    __syncthreads();
-    Fe s1 = block_sum_fr(a1, lds + 4);
+    Fe s0 = block_sum_fr(fs_to_fe(a0), lds), s1 = fe_zero();
+    if (HAS1) {
+        __syncthreads();
+        s1 = block_sum_fr(fs_to_fe(a1), lds + 4);
+    }
     if (threadIdx.x == 0) {
         fe_store(partial + 8 * (size_t)blockIdx.x, s0);
         fe_store(partial + 8 * (size_t)blockIdx.x + 4, s1);
     }
 }
-// sums `count` partial records of `width` Fr each into out[width]
-__global__ __launch_bounds__(256) void k_sum_partials(const uint64_t *__restrict__ partial, uint32_t count, uint32_t width,
+// sums `count` partial records of `width` Fr each into out[width]; times32: the records are sums of A(x) A(y) products
+// (1/32 of the A-form value): the total is multiplied by 32 (fr29.hpp C266)
+__global__ __launch_bounds__(256) void k_sum_partials(const uint64_t *__restrict__ partial, uint32_t count, uint32_t width, int times32,
                                                       uint64_t *__restrict__ out) {
     __shared__ Fe lds[4];
     for (uint32_t k = 0; k < width; k++) {
         Fe a = fe_zero();
         for (uint32_t i = threadIdx.x; i < count; i += 256) a = fe_add<FrCfg>(a, fe_load(partial + 4 * ((size_t)i * width + k)));
         Fe s = block_sum_fr(a, lds);
-        if (threadIdx.x == 0) fe_store(out + 4 * (size_t)k, s);
+        if (threadIdx.x == 0) {
+            if (times32) s = fs_to_fe(fs_mul(fs_from_fe(s), fs_c266()));
+            fe_store(out + 4 * (size_t)k, s);
+        }
         __syncthreads();
     }
 }
 
-// z^e from the table pw[k] = z^(2^k), e < 2^nbits
-HALO_DEV Fe pow_from_table(const uint64_t *__restrict__ pw, uint32_t e, int nbits) {
-    Fe acc = fe_one<FrCfg>();
-#pragma unroll 1
-    for (int k = 0; k < nbits; k++) {
-        if ((e >> k) & 1u) acc = fe_mul<FrCfg>(acc, fe_load(pw + 4 * (size_t)k));
+// ---- powers of one scalar: the window table the host prepares (upload_window_table)
+//   tab[d]               = A(z^d),          d < 16           (window 0 in A-form: seeds of k_powers)
+//   tab[16 + 16 k + d]   = N(z^(d 16^k)),   d < 16, k < nwin
+// z^e is a product of one entry per window: nwin - 1 products for any lane, whatever its exponent (a square-and-multiply
+// over a table of z^(2^k) ran up to 17 divergent products per lane: that, not bandwidth, was what k_powers and
+// k_poly_eval_partial spent their time on).
+constexpr int POW_WIN = 8;  // most windows: exponents below 2^32
+// every table entry is requested before the first product runs (the entries' addresses depend on e only): one memory
+// latency per seed, not one per window
+HALO_DEV Fs<4> window_power(const uint64_t *__restrict__ tab, uint32_t e, int nwin, bool a_form) {
+    Fe w[POW_WIN];
+#pragma unroll
+    for (int k = 0; k < POW_WIN; k++) {
+        uint32_t idx = k == 0 ? (a_form ? 0u : 16u) + (e & 15u) : 16u + 16u * (uint32_t)k + ((e >> (4 * k)) & 15u);
+        w[k] = fe_load(tab + 4 * (size_t)(k < nwin ? idx : 0u));
     }
+    Fs<4> acc = fs_from_fe(w[0]);
+#pragma unroll
+    for (int k = 1; k < POW_WIN; k++)
+        if (k < nwin) acc = fs_widen<4>(fs_mul(acc, fs_from_fe(w[k])));  // (nwin is a kernel argument: wave-uniform)
     return acc;
+}
+// elements per lane: a longer chain spreads the seed (nwin - 1 products) over more elements, a shorter one puts more
+// waves on the chip; measured at n = 2^20 (tools/fr_kernels.py with HALO_POW_E = 2 .. 32): k_powers 8, k_poly_eval_partial
+// 16, k_h_coeffs 4 (its "seed" is one product per four elements whatever the length)
+static int pow_chain_len(size_t n, int best) {
+    static const int forced = getenv("HALO_POW_E") ? atoi(getenv("HALO_POW_E")) : 0;  // development override
+    if (forced > 0) return forced;
+    int e = best;
+    while (e > 4 && n / (64 * (size_t)e) < 1024) e >>= 1;  // small inputs: at least a wave per SIMD
+    return e;
 }
 
 // ------------------------------------------------------------------ K6: out[i] = z^i
-__global__ __launch_bounds__(256) void k_powers(const uint64_t *__restrict__ pw, int nbits, uint32_t n, uint64_t *__restrict__ out) {
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t e0 = t * 8;
-    if (e0 >= n) return;
-    Fe z = fe_load(pw);
-    Fe cur = pow_from_table(pw, e0, nbits);
+// One product per 32 bytes written: VALU-bound (fr29.hpp: 5.3 TB/s if nothing else ran).  Lane l of a wave writes the
+// elements base + l + 64 k: every store instruction of the wave covers 2 KiB of consecutive addresses.
+__global__ __launch_bounds__(256) void k_powers(const uint64_t *__restrict__ tab, int nwin, int E, uint32_t n, FsArg z64, uint64_t *__restrict__ out) {
+    uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    uint32_t e = wave * (64u * (uint32_t)E) + lane;
+    if (e >= n) return;
+    Fs<2> cur = fs_tighten(window_power(tab, e, nwin, true));
+    Fs<1> step = from_nform(z64);
 #pragma unroll 1
-    for (int k = 0; k < 8 && e0 + k < n; k++) {
-        fe_store(out + 4 * (size_t)(e0 + k), cur);
-        cur = fe_mul<FrCfg>(cur, z);
+    for (int k = 0; k < E && e < n; k++, e += 64) {
+        fs_store(out + 4 * (size_t)e, cur);  // (a product's result is below 2 r: one conditional subtraction)
+        cur = fs_mul(cur, step);
     }
 }
 
-// ------------------------------------------------------------------ K9: p(z), 16 coefficients per lane
-__global__ __launch_bounds__(256) void k_poly_eval_partial(const uint64_t *__restrict__ coeffs, uint32_t len,
-                                                           const uint64_t *__restrict__ pw, int nbits, uint64_t *__restrict__ partial) {
+// ------------------------------------------------------------------ K9: p(z)
+// Lane l of a wave takes the coefficients base + l + 64 k, k < POW_E: a Horner chain in z^64 over coalesced loads (the
+// next coefficient is in flight while the current product runs), then one product with N(z^(base + l)).
+__global__ __launch_bounds__(256) void k_poly_eval_partial(const uint64_t *__restrict__ coeffs, uint32_t len, const uint64_t *__restrict__ tab,
+                                                           int nwin, int E, FsArg z64, uint64_t *__restrict__ partial) {
     __shared__ Fe lds[4];
-    Fe z = fe_load(pw);
-    Fe acc = fe_zero();
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t * 16 < len; t += gridDim.x * 256) {
-        uint32_t base = t * 16;
-        Fe h = fe_zero();
+    Fs<1> step = from_nform(z64);
+    Fs<2> acc = fs_zero<2>();
+    uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
+    for (uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6; (size_t)wave * (64u * (uint32_t)E) < len; wave += nwaves) {
+        uint32_t base = wave * (64u * (uint32_t)E) + lane;
+        if (base >= len) continue;
+        int top = (int)((len - 1 - base) >> 6);
+        if (top > E - 1) top = E - 1;
+        Fe nxt = fe_load(coeffs + 4 * (size_t)(base + 64u * (uint32_t)top));
+        Fs<2> h = fs_zero<2>();
 #pragma unroll 1
-        for (int k = 15; k >= 0; k--) {
-            h = fe_mul<FrCfg>(h, z);
-            if (base + k < len) h = fe_add<FrCfg>(h, fe_load(coeffs + 4 * (size_t)(base + k)));
+        for (int k = top; k >= 0; k--) {
+            Fe cur = nxt;
+            if (k > 0) nxt = fe_load(coeffs + 4 * (size_t)(base + 64u * (uint32_t)(k - 1)));
+            h = fs_tighten(fs_add(fs_mul(h, step), fs_from_fe(cur)));
         }
-        acc = fe_add<FrCfg>(acc, fe_mul<FrCfg>(h, pow_from_table(pw, base, nbits)));
+        acc = fs_tighten(fs_add(acc, fs_mul(h, window_power(tab, base, nwin, false))));
     }
-    Fe s = block_sum_fr(acc, lds);
+    Fe s = block_sum_fr(fs_to_fe(acc), lds);
     if (threadIdx.x == 0) fe_store(partial + 4 * (size_t)blockIdx.x, s);
 }
 
 // ------------------------------------------------------------------ K7: h coefficients from three 256-entry tables
-__global__ __launch_bounds__(256) void k_h_coeffs(const uint64_t *__restrict__ tab /* low | mid | high, 256 x 4 each */, uint32_t n,
-                                                  int accumulate, uint64_t *__restrict__ out) {
-    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+// tab = low (A-form) | mid | high (N-form), 256 x 4 words each; coefficient k = low[k & 255] * mid[(k >> 8) & 255] * high[k >> 16].
+// Lane l of a wave takes k = base + l + 64 j: (k >> 8) is the same for the whole wave and changes every fourth step,
+// so mid * high is one product per four elements and low * (mid high) the only product per element.
+__global__ __launch_bounds__(256) void k_h_coeffs(const uint64_t *__restrict__ tab, uint32_t n, int E, int accumulate, uint64_t *__restrict__ out) {
+    uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    uint32_t k = wave * (64u * (uint32_t)E) + lane;
     if (k >= n) return;
-    Fe lo = fe_load(tab + 4 * (size_t)(k & 255u));
-    Fe mi = fe_load(tab + 4 * (size_t)(256 + ((k >> 8) & 255u)));
-    Fe hi = fe_load(tab + 4 * (size_t)(512 + ((k >> 16) & 255u)));
-    Fe v = fe_mul<FrCfg>(fe_mul<FrCfg>(lo, mi), hi);
-    if (accumulate) v = fe_add<FrCfg>(v, fe_load(out + 4 * (size_t)k));
-    fe_store(out + 4 * (size_t)k, v);
+    Fs<4> hm = fs_zero<4>();
+#pragma unroll 1
+    for (int j = 0; j < E && k < n; j++, k += 64) {
+        if ((j & 3) == 0) {
+            uint32_t kk = __builtin_amdgcn_readfirstlane(k);  // wave-uniform: (k >> 8) does not depend on the lane
+            hm = fs_widen<4>(fs_mul(fs_load(tab + 4 * (size_t)(256 + ((kk >> 8) & 255u))), fs_load(tab + 4 * (size_t)(512 + ((kk >> 16) & 255u)))));
+        }
+        Fs<2> v = fs_mul(fs_load(tab + 4 * (size_t)(k & 255u)), hm);
+        if (accumulate) fs_store(out + 4 * (size_t)k, fs_add(v, fs_load(out + 4 * (size_t)k)));
+        else fs_store(out + 4 * (size_t)k, v);
+    }
 }
 
 // ------------------------------------------------------------------ K8: HPoly::eval, one polynomial per lane
@@ -493,12 +591,12 @@ __global__ __launch_bounds__(256) void k_pbar(const uint64_t *__restrict__ q, ui
     Fe hi = (i < deg) ? fe_load(q + 4 * (size_t)i) : fe_zero();
     fe_store(out + 4 * (size_t)i, fe_sub<FrCfg>(lo, fe_mul<FrCfg>(z, hi)));
 }
-// y[i] += a * x[i]   (p' = p + alpha p_bar, pcdl.rs:156)
-__global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const uint64_t *__restrict__ x, uint32_t n, FeArg aarg) {
+// y[i] += a * x[i]   (p' = p + alpha p_bar, pcdl.rs:156): 96 bytes moved per product, HBM-bound
+__global__ __launch_bounds__(256) void k_axpy(uint64_t *__restrict__ y, const uint64_t *__restrict__ x, uint32_t n, FsArg aarg) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Fe a = from_arg(aarg);
-    fe_store(y + 4 * (size_t)i, fe_add<FrCfg>(fe_load(y + 4 * (size_t)i), fe_mul<FrCfg>(a, fe_load(x + 4 * (size_t)i))));
+    Fe yv = fe_load(y + 4 * (size_t)i), xv = fe_load(x + 4 * (size_t)i);
+    fs_store(y + 4 * (size_t)i, fs_add(fs_from_fe(yv), fs_mul(fs_from_fe(xv), from_nform(aarg))));
 }
 
 
@@ -578,8 +676,8 @@ int ipa_fold_points4(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
 }
 int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, const host::Fr &xi, const host::Fr &xi_inv) {
     if (m == 0) return HALO_OK;
-    HALO_LAUNCH(ctx, "k_fold_scalars", k_fold_scalars, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_c, d_z, (uint32_t)m, to_arg(xi),
-                to_arg(xi_inv));
+    HALO_LAUNCH(ctx, "k_fold_scalars", k_fold_scalars, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, d_c, d_z, (uint32_t)m, to_nform(xi),
+                to_nform(xi_inv));
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }
@@ -591,14 +689,23 @@ static unsigned reduce_blocks(size_t work_items) {
     return (unsigned)nb;
 }
 
+// two elements per lane and trip, at most 512 blocks (two waves per SIMD): the lanes of a large dot product run several trips
+static unsigned dot_blocks(size_t m) {
+    size_t nb = ((m + 1) / 2 + 255) / 256;
+    if (nb > 512) nb = 512;
+    if (nb == 0) nb = 1;
+    return (unsigned)nb;
+}
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
             host::Fr out[2]) {
     out[0] = out[1] = host::Fr::zero();
     if (m == 0) return HALO_OK;
-    unsigned nb = reduce_blocks(m);
+    if (!xs0) { set_error("dot2: the first pair of vectors is required"); return HALO_E_ARG; }
+    unsigned nb = dot_blocks(m);
     uint64_t *partial = ctx->d_tmp_c;  // >= 1024 * 8 words
-    HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial, dim3(nb), dim3(256), 0, xs0, ys0, xs1, ys1, (uint32_t)m, partial);
-    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 2u, partial + 8 * 1024);
+    if (xs1) HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial<true>, dim3(nb), dim3(256), 0, xs0, ys0, xs1, ys1, (uint32_t)m, partial);
+    else HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial<false>, dim3(nb), dim3(256), 0, xs0, ys0, xs1, ys1, (uint32_t)m, partial);
+    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 2u, 1, partial + 8 * 1024);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ctx->h_pinned, partial + 8 * 1024, 64, hipMemcpyDeviceToHost, ctx->stream));
     HALO_HIP(hipStreamSynchronize(ctx->stream));
@@ -607,28 +714,47 @@ int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint6
     return HALO_OK;
 }
 
-// pw[k] = z^(2^k), k < 32, staged through the pinned page (slot at word 64)
-static int upload_pow_table(halo_ctx *ctx, const host::Fr &z, uint64_t *d_pw) {
-    host::Fr cur = z;
-    uint64_t *h = ctx->h_pinned + 64;
-    for (int k = 0; k < 32; ++k) { cur.store(h + 4 * k); cur = cur.sqr(); }
-    HALO_HIP(hipMemcpyAsync(d_pw, h, 32 * 32, hipMemcpyHostToDevice, ctx->stream));
-    HALO_HIP(hipStreamSynchronize(ctx->stream));  // the pinned page is reused by the next call
-    return HALO_OK;
-}
+// Window table of z (see window_power): 16 A-form entries, then nwin x 16 N-form entries, staged through pinned memory.
+// ~32 nwin host products (a few microseconds).
 static int bits_for(size_t n) {
     int b = 0;
     while (((size_t)1 << b) < n) b++;
     return b < 1 ? 1 : b;
 }
+static int upload_window_table(halo_ctx *ctx, const host::Fr &z, int nwin, uint64_t *d_tab, host::Fr *z64) {
+    uint64_t *h = ctx->h_wintab;  // pinned, 1024 words: nwin <= 15
+    const host::Fr k32 = host::Fr::from_u64(32);
+    host::Fr base = z;  // z^(16^k)
+    for (int k = 0; k < nwin; ++k) {
+        host::Fr cur = host::Fr::one();
+        for (int d = 0; d < 16; ++d) {
+            if (k == 0) cur.store(h + 4 * d);
+            (cur * k32).store(h + 4 * (16 + 16 * k + d));
+            cur = cur * base;
+        }
+        base = cur;  // z^(16^(k+1))
+    }
+    host::Fr t = z;
+    for (int i = 0; i < 6; ++i) t = t.sqr();
+    *z64 = t;
+    HALO_HIP(hipMemcpyAsync(d_tab, h, (size_t)64 * (1 + nwin) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HALO_HIP(hipStreamSynchronize(ctx->stream));  // the staging memory is reused by the next call
+    return HALO_OK;
+}
+static unsigned wave_blocks(size_t n, int E) {  // blocks of 4 waves, a wave per 64 * E elements
+    size_t waves = (n + 64 * (size_t)E - 1) / (64 * (size_t)E);
+    return (unsigned)((waves + 3) / 4);
+}
 
 int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out) {
     if (n == 0) return HALO_OK;
-    uint64_t *d_pw = ctx->d_tmp_c + 8 * 1024 + 64;
-    int rc = upload_pow_table(ctx, z, d_pw);
+    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 64;
+    int nwin = (bits_for(n) + 3) / 4;
+    host::Fr z64;
+    int rc = upload_window_table(ctx, z, nwin, d_tab, &z64);
     if (rc) return rc;
-    size_t threads = (n + 7) / 8;
-    HALO_LAUNCH(ctx, "k_powers", k_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, d_pw, bits_for(n), (uint32_t)n, d_out);
+    int E = pow_chain_len(n, 8);
+    HALO_LAUNCH(ctx, "k_powers", k_powers, dim3(wave_blocks(n, E)), dim3(256), 0, d_tab, nwin, E, (uint32_t)n, to_nform(z64), d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }
@@ -636,14 +762,18 @@ int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out) {
 int fr_poly_eval(halo_ctx *ctx, const uint64_t *d_coeffs, size_t len, const host::Fr &z, host::Fr *out) {
     *out = host::Fr::zero();
     if (len == 0) return HALO_OK;
-    uint64_t *d_pw = ctx->d_tmp_c + 8 * 1024 + 64;
-    int rc = upload_pow_table(ctx, z, d_pw);
+    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 64;
+    int nwin = (bits_for(len) + 3) / 4;
+    host::Fr z64;
+    int rc = upload_window_table(ctx, z, nwin, d_tab, &z64);
     if (rc) return rc;
-    unsigned nb = reduce_blocks((len + 15) / 16);
+    int E = pow_chain_len(len, 16);
+    unsigned nb = wave_blocks(len, E);
+    if (nb > 1024) nb = 1024;
     uint64_t *partial = ctx->d_tmp_c;
-    HALO_LAUNCH(ctx, "k_poly_eval_partial", k_poly_eval_partial, dim3(nb), dim3(256), 0, d_coeffs, (uint32_t)len, d_pw, bits_for(len),
+    HALO_LAUNCH(ctx, "k_poly_eval_partial", k_poly_eval_partial, dim3(nb), dim3(256), 0, d_coeffs, (uint32_t)len, d_tab, nwin, E, to_nform(z64),
                 partial);
-    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 1u, partial + 8 * 1024);
+    HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 1u, 0, partial + 8 * 1024);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ctx->h_pinned, partial + 8 * 1024, 32, hipMemcpyDeviceToHost, ctx->stream));
     HALO_HIP(hipStreamSynchronize(ctx->stream));
@@ -667,15 +797,62 @@ int h_coeffs_dev(halo_ctx *ctx, const host::Fr *xis, size_t lg_n, const host::Fr
             len *= 2;
         }
         if (level == 2 && len == 1) t[0] = scale;
-        for (size_t k = 0; k < 256; ++k) t[k].store(&tab[((size_t)level * 256 + k) * 4]);
+        // low table in A-form (what the kernel multiplies INTO), mid and high as N-form multipliers (fr29.hpp): 32 x
+        const host::Fr k32 = host::Fr::from_u64(32);
+        for (size_t k = 0; k < 256; ++k) (level == 0 ? t[k] : t[k] * k32).store(&tab[((size_t)level * 256 + k) * 4]);
     }
-    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 256;
+    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 1024;  // (the window table of fr_powers / fr_poly_eval sits below)
     HALO_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HALO_HIP(hipStreamSynchronize(ctx->stream));  // `tab` is pageable and dies at return
     size_t n = (size_t)1 << lg_n;
-    HALO_LAUNCH(ctx, "k_h_coeffs", k_h_coeffs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_tab, (uint32_t)n, accumulate ? 1 : 0,
-                d_out);
+    int E = pow_chain_len(n, 4);
+    HALO_LAUNCH(ctx, "k_h_coeffs", k_h_coeffs, dim3(wave_blocks(n, E)), dim3(256), 0, d_tab, (uint32_t)n, E, accumulate ? 1 : 0, d_out);
     HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+
+// Measurement hook (halo_bench_fr_kernel): `reps` back-to-back launches of ONE of the bandwidth-side kernels over n elements
+// of the context's scratch buffers (any 256-bit patterns are valid operands), nothing else on the stream and no host
+// round trip in between -- the steady-state duration a profiler reads off, not the first launch after an idle gap.
+int bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps) {
+    if (n == 0 || n > (ctx->n < 64 ? 64 : ctx->n) || reps < 1) { set_error("bench_fr_kernel: n must be in [1, context size]"); return HALO_E_ARG; }
+    uint64_t *a = ctx->d_tmp_a, *b = ctx->d_tmp_b, *c = ctx->d_tmp_b + 4 * n, *d = ctx->d_tmp_b + 8 * n;  // n x 4 words each (d_tmp_b: 16 n words)
+    host::Fr z = host::Fr::from_u64(0x1234567) * host::Fr::from_u64(0x89abcdef), z64;
+    uint64_t *d_tab = ctx->d_tmp_c + 8 * 1024 + 64, *partial = ctx->d_tmp_c;
+    int nwin = (bits_for(n) + 3) / 4;
+    int rc = rng_scalars_dev(ctx, 0xF00D, n, b);
+    if (!rc) rc = rng_scalars_dev(ctx, 0xBEEF, n, c);
+    if (!rc) rc = rng_scalars_dev(ctx, 0xCAFE, n, d);
+    if (!rc) rc = upload_window_table(ctx, z, nwin, d_tab, &z64);
+    if (rc) return rc;
+    size_t m = n / 2 ? n / 2 : 1;
+    for (int r = 0; r < reps; ++r) {
+        switch (which) {
+            case 0: { int E = pow_chain_len(n, 8); HALO_LAUNCH(ctx, "k_powers", k_powers, dim3(wave_blocks(n, E)), dim3(256), 0, d_tab, nwin, E, (uint32_t)n, to_nform(z64), a); break; }
+            case 1: {
+                int E = pow_chain_len(n, 16);
+                unsigned nb = wave_blocks(n, E);
+                if (nb > 1024) nb = 1024;
+                HALO_LAUNCH(ctx, "k_poly_eval_partial", k_poly_eval_partial, dim3(nb), dim3(256), 0, b, (uint32_t)n, d_tab, nwin, E, to_nform(z64), partial);
+                break;
+            }
+            case 2: HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial<false>, dim3(dot_blocks(n)), dim3(256), 0, b, c, (const uint64_t *)nullptr,
+                                (const uint64_t *)nullptr, (uint32_t)n, partial); break;
+            case 3: HALO_LAUNCH(ctx, "k_dot2_partial", k_dot2_partial<true>, dim3(dot_blocks(m)), dim3(256), 0, b + 4 * m, c, b, c + 4 * m, (uint32_t)m, partial); break;
+            case 4: {
+                int E = pow_chain_len(n, 4);
+                // (the table region holds the window table: valid field elements, which is all the kernel needs)
+                HALO_LAUNCH(ctx, "k_h_coeffs", k_h_coeffs, dim3(wave_blocks(n, E)), dim3(256), 0, ctx->d_tmp_c + 8 * 1024 + 1024, (uint32_t)n, E, 0, a);
+                break;
+            }
+            case 5: HALO_LAUNCH(ctx, "k_fold_scalars", k_fold_scalars, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, b, c, (uint32_t)m, to_nform(z), to_nform(z64)); break;
+            case 6: HALO_LAUNCH(ctx, "k_axpy", k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b, c, (uint32_t)n, to_nform(z)); break;
+            default: set_error("bench_fr_kernel: which must be 0..6"); return HALO_E_ARG;
+        }
+    }
+    HALO_HIP(hipGetLastError());
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof.on) ctx->prof.collect();
     return HALO_OK;
 }
 
@@ -713,7 +890,7 @@ int pbar_dev(halo_ctx *ctx, const uint64_t *d_q, size_t deg, const host::Fr &z, 
 }
 int axpy_dev(halo_ctx *ctx, uint64_t *d_y, const uint64_t *d_x, size_t n, const host::Fr &a) {
     if (n == 0) return HALO_OK;
-    HALO_LAUNCH(ctx, "k_axpy", k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_y, d_x, (uint32_t)n, to_arg(a));
+    HALO_LAUNCH(ctx, "k_axpy", k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_y, d_x, (uint32_t)n, to_nform(a));
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

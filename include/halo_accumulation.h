@@ -231,6 +231,11 @@ int halo_prof_reset(halo_ctx *ctx);
 /* number of distinct kernels seen; name/total ms/launch count of entry i */
 int halo_prof_count(halo_ctx *ctx);
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
+/* `reps` back-to-back launches of one bandwidth-side Fr kernel over n elements of the context's scratch memory (no host
+ * round trip in between): which = 0 k_powers, 1 k_poly_eval_partial, 2 k_dot2_partial (one pair of vectors), 3 k_dot2_partial
+ * (the two pairs of an IPA round, m = n / 2), 4 k_h_coeffs, 5 k_fold_scalars (m = n / 2), 6 k_axpy.  For rocprofv3 / the
+ * event profiler: steady-state kernel durations, the figures of bench.py's hbm_kernels block. */
+int halo_bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps);
 /* n uniform scalars (Montgomery limbs) of the SplitMix64 stream, written to DEVICE memory: the
  * synthetic-input generator of the benchmarks (element i = draws 4i+1..4i+4 after *rng_state,
  * little-endian, reduced mod r); *rng_state advances as a sequential stream would */
