@@ -94,7 +94,10 @@ def main():
     else:
         # index shard: this rank's block of the key (main.rs:35-45: G_i = hash(i + 2)) and of the scalars
         (lo, hi), part, parts = shard_range(n, rank, world), 0, 1
+    torch.cuda.synchronize()
+    t_setup0 = time.perf_counter()
     ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=gpu)
+    t_setup_urs = time.perf_counter() - t_setup0  # the key derived on the device (k_urs) + workspace of slot 0
     # scalars: SplitMix64 seed ...02, generated on the device by the library's own
     # generator.  MSM j of a launch takes the j-th block of n scalars of that stream (4 draws per scalar).
     GAMMA, MASK, SEED = 0x9E3779B97F4A7C15, (1 << 64) - 1, 0x48414C4F00000002
@@ -114,6 +117,18 @@ def main():
         # first collective now: the communicator's lazy allocations happen before any launch graph exists
         gather.gather_batch([np.zeros(12, dtype=np.uint64)] * batch)
 
+    # one-time cost of the first MSM over the key (fixed-base table build, first-use allocations) -- and the latency of one
+    # MSM alone (nothing else in flight, scalars resident): what a single-threaded caller of the reference API sees per call
+    t0 = time.perf_counter()
+    first = ctx.msm_dev(ptrs[0], hi - lo) if not window_mode else None
+    t_first = time.perf_counter() - t0
+    solo = []
+    if not window_mode:
+        for _ in range(12):
+            t0 = time.perf_counter()
+            again = ctx.msm_dev(ptrs[0], hi - lo)
+            solo.append(time.perf_counter() - t0)
+        assert again.tolist() == first.tolist()
     cfg = {"depth": args.depth}
     outs = [None] * batch  # latest combined result per scalar set
 
@@ -260,6 +275,12 @@ def main():
                          "kernel_ms": kern_s * 1e3, "kernel_ms_while_%d_launches_in_flight" % args.depth: ovl_ms / max(ovl_cnt, 1),
                          "algorithmic_bytes": alg_bytes, "valu": valu,
                          "note": "integer-VALU-bound kernel: see DESIGN.md for the VALU roofline"},
+            "solo_latency_ms": (sorted(solo)[len(solo) // 2] * 1e3 if solo else None),
+            "context_setup_ms": {"key_on_device_and_workspace": t_setup_urs * 1e3,
+                                 "first_msm_incl_table_build": t_first * 1e3,
+                                 "note": "one-time: halo_ctx_create_urs (k_urs over this rank's block + slot-0 workspace), then the first MSM, which "
+                                         "builds the fixed-base table (k_table_step per window) before it runs"},
+            "table_bytes": ((13 if hi - lo >= (1 << 20) else 15) * 128 * (hi - lo) if (not window_mode and hi - lo >= (1 << 17)) else 0),
             "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
         }
 
@@ -280,8 +301,29 @@ def main():
             got_h = ctx.msm(sc_host)
         h2d_dt = (time.perf_counter() - t0) / 8
         assert got_h.tolist() == out.tolist()
+        # the same through the asynchronous halves (halo_msm_begin / halo_msm_end): the copy of the next MSM's scalars runs while
+        # the current MSM's kernels do
+        K, D = 16, 3
+        ctx.msm_begin(0, sc_host); ctx.msm_end(0)
+        t0 = time.perf_counter()
+        for k in range(K + D):
+            if k >= D:
+                got_p = ctx.msm_end(k % D)
+            if k < K:
+                ctx.msm_begin(k % D, sc_host)
+        pipe_dt = (time.perf_counter() - t0) / K
+        assert got_p.tolist() == out.tolist()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            d_tmp = torch.from_numpy(sc_host.view(np.int64)).to(dev)
+            torch.cuda.synchronize()
+        copy_dt = (time.perf_counter() - t0) / 4
         result["end_to_end_host_scalars"] = {"value": 1.0 / h2d_dt, "unit": "MSM/s", "ms": h2d_dt * 1e3,
-                                             "note": "halo_msm: scalars copied from pageable host memory each call, one MSM in flight"}
+                                             "pipelined_value": 1.0 / pipe_dt, "pipelined_ms": pipe_dt * 1e3,
+                                             "h2d_copy_alone_ms": copy_dt * 1e3, "h2d_copy_GBs": sc_host.nbytes / copy_dt / 1e9,
+                                             "note": "halo_msm: %d MiB of scalars copied from pageable host memory each call, one MSM in flight (a call is "
+                                                     "the copy + the latency of one MSM); pipelined: halo_msm_begin/_end on %d slots, the next copy under the "
+                                                     "current kernels; h2d_copy_alone: the same buffer through torch, for scale" % (sc_host.nbytes >> 20, D)}
         if args.cpu_msms > 0:
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
             sc_all = sc_host

@@ -49,6 +49,8 @@ _SIGS = {
     "halo_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "halo_public_points": (C.c_int, [u64p, u64p]),
     "halo_msm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_int, u64p]),
+    "halo_msm_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, u64p, C.c_int]),
+    "halo_msm_end": (C.c_int, [C.c_void_p, C.c_int, u64p]),
     "halo_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, u64p]),
     "halo_msm_dev_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "halo_msm_dev_end": (C.c_int, [C.c_void_p, C.c_int, u64p]),
@@ -221,6 +223,16 @@ class Context:
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros(12, dtype=np.uint64)
         check(self.lib.halo_msm(self.h, off, scalars.shape[0], ptr(scalars), int(mont), ptr(out)))
+        return out
+
+    def msm_begin(self, slot: int, scalars, off=0, mont=True):
+        """host scalars, asynchronous: copy + launch on `slot`; msm_end(slot) collects"""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        check(self.lib.halo_msm_begin(self.h, slot, off, scalars.shape[0], ptr(scalars), int(mont)))
+
+    def msm_end(self, slot: int):
+        out = np.zeros(12, dtype=np.uint64)
+        check(self.lib.halo_msm_end(self.h, slot, ptr(out)))
         return out
 
     def msm_dev(self, dptr: int, n: int, off=0, mont=True):

@@ -275,6 +275,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_poly);
     (void)hipFree(ctx->d_poly2);
     (void)hipFree(ctx->d_verify);
+    for (auto p : ctx->d_slot_scalars) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_wintab) (void)hipHostFree(ctx->h_wintab);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
@@ -361,12 +362,31 @@ int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out)
     return HALO_OK;
 }
 
+// scalars in host memory: copied on the slot's own stream right in front of the launch sequence (no host round trip in
+// between), into a per-slot device buffer so that launches on different slots overlap with each other's copies
+static int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont) {
+    if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
+    if (off + n > ctx->n || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    if (ctx->wss[slot].in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    if (!ctx->d_slot_scalars[slot]) {
+        alloc_epoch_bump(ctx);
+        HALO_HIP(hipMalloc(&ctx->d_slot_scalars[slot], (ctx->n < 64 ? 64 : ctx->n) * 32));
+    }
+    if (n) HALO_HIP(hipMemcpyAsync(ctx->d_slot_scalars[slot], scalars, n * 32, hipMemcpyHostToDevice, ctx->streams[slot]));
+    return msm_enqueue(ctx, slot, ctx->d_bases + 32 * off, ctx->d_slot_scalars[slot], mont != 0, n);
+}
+int halo_msm_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont) {
+    HALO_CTX(ctx);
+    return msm_host_begin(ctx, slot, off, n, scalars, mont);
+}
+int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out[12]) { return halo_msm_dev_end(ctx, slot, out); }
+
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int mont, uint64_t out[12]) {
     HALO_CTX(ctx);
-    if (off + n > ctx->n || !out || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
-    int rc = upload(ctx, ctx->d_tmp_a, scalars, n * 4);
+    if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
+    int rc = msm_host_begin(ctx, 0, off, n, scalars, mont);
     if (rc) return rc;
-    return halo_msm_dev(ctx, off, n, ctx->d_tmp_a, mont, out);
+    return halo_msm_dev_end(ctx, 0, out);
 }
 
 int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out[12]) {

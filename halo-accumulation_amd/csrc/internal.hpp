@@ -240,6 +240,7 @@ struct halo_ctx {
     size_t tmp_words = 0;
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
     uint64_t *h_wintab = nullptr;  // pinned staging of a window table of powers (ipa.hip upload_window_table), 8 KiB
+    uint64_t *d_slot_scalars[HALO_SLOTS] = {};  // host-scalar MSMs (halo_msm, halo_msm_begin): one staging buffer of n x 4 words per slot, first use
     uint64_t *d_verify = nullptr;  // staging of the batched verifier (points, scalars, challenges, results), grown on demand
     size_t verify_words = 0;
     // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover

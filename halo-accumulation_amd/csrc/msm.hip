@@ -488,14 +488,27 @@ TblPlan table_plan(size_t key_n) {
     return t;
 }
 
-// next[i] = 2^c * prev[i], affine in, affine out (one Fermat inversion per point: paid once per context)
+// next[i] = 2^c * prev[i], affine in, affine out.  A lane takes TBL_E points (i, i + stride, ...) and brings them back to
+// affine with one shared inversion (curve.hpp jac_batch_to_aff): the inversion was 70 % of a point's work.
+constexpr int TBL_E = 4;
 __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__ prev, uint32_t n, int c, uint32_t *__restrict__ next) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    JacN p = jac_from_aff(aff_load(prev + AFF_STRIDE * (size_t)i));
+    uint32_t t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (t >= n) return;
+    JacN p[TBL_E];
+    static_for<0, TBL_E>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        uint32_t i = t + (uint32_t)e * stride;
+        p[e] = i < n ? jac_from_aff(aff_load(prev + AFF_STRIDE * (size_t)i)) : jac_inf();
+    });
 #pragma unroll 1
-    for (int k = 0; k < c; k++) p = jac_dbl(p);
-    aff_store(next + AFF_STRIDE * (size_t)i, jac_to_aff(p));
+    for (int k = 0; k < c; k++) static_for<0, TBL_E>([&](auto ic) { p[decltype(ic)::value] = jac_dbl(p[decltype(ic)::value]); });
+    AffN a[TBL_E];
+    jac_batch_to_aff(p, a);
+    static_for<0, TBL_E>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        uint32_t i = t + (uint32_t)e * stride;
+        if (i < n) aff_store(next + AFF_STRIDE * (size_t)i, a[e]);
+    });
 }
 
 // signed 20-bit digits, u32 [w][i]: (|d| - 1) | sign << 31, TDIGIT_NONE for zero; block 0 clears the launch's small state
@@ -1107,11 +1120,23 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
 // The segments of a window are combined by k_smsm_final (smsm.hip, quad-parallel): see quad_final_enqueue.
 
 // ------------------------------------------------------------------------------ K10 / K11 / format conversion
-// arkworks Jacobian words -> native affine (one Fermat inversion per lane)
+// arkworks Jacobian words -> native affine: TBL_E points per lane, one shared Fermat inversion (jac_batch_to_aff)
 __global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint32_t *__restrict__ out) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    aff_store(out + AFF_STRIDE * (size_t)i, jac_to_aff(jac_from_words(jac + 12 * (size_t)i)));
+    uint32_t t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    if (t >= n) return;
+    JacN p[TBL_E];
+    static_for<0, TBL_E>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        uint32_t i = t + (uint32_t)e * stride;
+        p[e] = i < n ? jac_from_words(jac + 12 * (size_t)i) : jac_inf();
+    });
+    AffN a[TBL_E];
+    jac_batch_to_aff(p, a);
+    static_for<0, TBL_E>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        uint32_t i = t + (uint32_t)e * stride;
+        if (i < n) aff_store(out + AFF_STRIDE * (size_t)i, a[e]);
+    });
 }
 // arkworks affine words (n x 8 u64) -> native table (n x 20 words)
 __global__ __launch_bounds__(256) void k_aff_to_native(const uint64_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ out) {
@@ -1266,7 +1291,7 @@ int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_
 
 int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    dim3 grid((unsigned)(((n + TBL_E - 1) / TBL_E + 255) / 256)), block(256);
     HALO_LAUNCH(ctx, "k_batch_to_affine", k_batch_to_affine, grid, block, 0, d_jac, (uint32_t)n, d_out);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
@@ -1600,8 +1625,8 @@ static int table_build(halo_ctx *ctx) {
         if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)tbl, (size_t)tp.W * n * 128);
         e = hipMemcpyAsync(tbl, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream);
         for (int w = 1; w < tp.W && e == hipSuccess; ++w) {
-            HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tbl + (size_t)(w - 1) * n * AFF_STRIDE, (uint32_t)n,
-                        tp.c, tbl + (size_t)w * n * AFF_STRIDE);
+            HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)(((n + TBL_E - 1) / TBL_E + 255) / 256)), dim3(256), 0,
+                        tbl + (size_t)(w - 1) * n * AFF_STRIDE, (uint32_t)n, tp.c, tbl + (size_t)w * n * AFF_STRIDE);
             e = hipGetLastError();
         }
         hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -68,6 +68,12 @@ int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
  * scalars_are_mont = 1: arkworks' in-memory Fr (Montgomery limbs); 0: plain little-endian integers below 2^255
  * (canonical Fr values; an unreduced value in [r, 2^255) is taken as it is, which gives the same point). */
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
+/* Asynchronous halves of halo_msm (scalars in HOST memory): begin() copies the scalars to the device on the slot's own
+ * stream and enqueues the launch sequence behind the copy, end() waits and combines.  With two or more slots a caller
+ * overlaps the copy of the next MSM (32 MiB at n = 2^20: PCIe time) with the kernels of the current one.  The scalars may be
+ * reused as soon as begin() returns if they live in pageable memory; pinned memory must stay untouched until end(). */
+int halo_msm_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont);
+int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out_jac[12]);
 /* same, scalars already in device memory (n x 4 limbs, 32-byte aligned device pointer) */
 int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int scalars_are_mont, uint64_t out_jac[12]);
 /* Asynchronous halves of halo_msm_dev, for overlapping independent MSMs: `slot` (0..3) selects
@@ -92,7 +98,7 @@ int halo_msm_dev_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, cons
                              int scalars_are_mont, int part, int parts);
 int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out_jac);
 /* point_dot (group.rs:18-21): arbitrary Jacobian points (m x 12 limbs); they are brought to
- * affine on the device (one Montgomery batch inversion per 256-point block; the reference runs m separate ones). */
+ * affine on the device (Montgomery batch inversion: one field inversion per four points; the reference runs m). */
 int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out_jac[12]);
 /* point_dot_affine (group.rs:24-26) for bases that are NOT a stretch of the context's key: pedersen::commit
  * (pedersen.rs:6-20) is public API over any `&[PallasAffine]`, and the reference's own test_homomorphism_property

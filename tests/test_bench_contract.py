@@ -37,6 +37,11 @@ def test_bench_emits_contract_json():
     assert r["timed_region"]["repetitions"] >= 1 and r["timed_region"]["reported"] == "median"
     assert r["end_to_end_host_scalars"]["value"] > 0 and r["asdl_chain"]["all_accepted"] is True
     assert "cpu_model" in cb and r["cpu_baseline_all_cores"]["cores"] >= 1
+    assert r["solo_latency_ms"] > 0 and r["context_setup_ms"]["first_msm_incl_table_build"] > 0 and "table_bytes" in r
+    assert r["end_to_end_host_scalars"]["pipelined_value"] > 0
+    hk = r["hbm_kernels"]["kernels"]
+    assert set(hk) == {"k_powers", "k_poly_eval_partial", "k_dot2_partial", "k_h_coeffs", "k_fold_scalars", "k_axpy"}
+    assert all(v["achieved"] > 0 and abs(v["frac"] - v["achieved"] / 8000.0) < 1e-12 for v in hk.values())
 
 
 def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():

@@ -577,6 +577,20 @@ def test_msm_2_20_adversarial_scalars_stay_fast_and_exact(ctx1m):
     assert dt_one < 0.5 and dt_same < 0.5, (dt_one, dt_same)
 
 
+def test_msm_host_scalars_async_halves(hal, ctx16k, urs4096):
+    """halo_msm_begin / halo_msm_end: host scalars, several slots in flight, results equal halo_msm's and the oracle's;
+    a busy slot is refused"""
+    sets = [orc.rng_scalars(0xA5 + k, 4096)[0] for k in range(4)]
+    for k in range(4):
+        ctx16k.msm_begin(k, sets[k], off=k * 8)
+    with pytest.raises(hal.HaloError):
+        ctx16k.msm_begin(2, sets[0])
+    got = [ctx16k.msm_end(k) for k in range(4)]
+    gs = ctx16k.read_bases()
+    for k in range(4):
+        assert got[k].tolist() == ctx16k.msm(sets[k], off=k * 8).tolist() == orc.msm_affine(gs[k * 8:k * 8 + 4096], sets[k]).tolist()
+
+
 def test_msm_pipelined_slots_agree(ctx1m):
     """halo_msm_dev_begin/_end on all four slots, interleaved, equals the synchronous call."""
     import torch
