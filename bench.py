@@ -29,6 +29,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: everything else any library prints there during the run (RCCL announces
+    # its version on stdout when a communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -42,6 +47,10 @@ def main():
     ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
+    ap.add_argument("--one-process", action="store_true",
+                    help="--gpus N from ONE process (no torch.distributed): a multi-device context (halo_ctx_create_urs_multi), one "
+                         "index-block shard per GPU, partial points added on the host")
+    ap.add_argument("--devices", default="", help="--one-process: comma-separated device ids (default 0..N-1; ids may repeat for a rehearsal)")
     ap.add_argument("--fr-reps", type=int, default=20, help="back-to-back launches of each bandwidth-side Fr kernel at N=1 (0 = skip)")
     ap.add_argument("--asdl-steps", type=int, default=8, help="ASDL chain steps (random_instance + prover + verifier, then one decider) at N=1 (0 = skip)")
     args = ap.parse_args()
@@ -63,7 +72,13 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    one_proc = args.one_process
+    assert world == (1 if one_proc else args.gpus), "launch with torch.distributed.run --nproc-per-node == --gpus (or --one-process)"
+    devices = None
+    if one_proc:
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else [k % max(torch.cuda.device_count(), 1) for k in range(args.gpus)]
+        assert len(devices) == args.gpus
+        gpu = devices[0]
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
@@ -86,6 +101,8 @@ def main():
         batch = 8 if per_rank < (1 << 18) else 4 if per_rank < (1 << 19) else 2 if per_rank < (1 << 20) else 1
     else:
         batch = 1 if world <= 2 else 4
+    if one_proc:
+        batch = 1
     window_mode = world > 1 and args.shard == "window"
     if window_mode:
         # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes
@@ -96,7 +113,7 @@ def main():
         (lo, hi), part, parts = shard_range(n, rank, world), 0, 1
     torch.cuda.synchronize()
     t_setup0 = time.perf_counter()
-    ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=gpu)
+    ctx = h._lib.Context(urs_n=hi - lo, first_index=2 + lo, device=gpu) if not one_proc else h._lib.Context(urs_n=n, devices=devices)
     t_setup_urs = time.perf_counter() - t_setup0  # the key derived on the device (k_urs) + workspace of slot 0
     # scalars: SplitMix64 seed ...02, generated on the device by the library's own
     # generator.  MSM j of a launch takes the j-th block of n scalars of that stream (4 draws per scalar).
@@ -143,7 +160,7 @@ def main():
 
         def finish():
             slot, m = pending.pop(0)
-            partials = ctx.msm_dev_batch_end(slot, m)
+            partials = [ctx.msm_dev_end(slot)] if one_proc else ctx.msm_dev_batch_end(slot, m)
             gathers.append(gather.gather_start([partials[j] for j in range(m)]))  # one all-gather per launch, asynchronous
             while len(gathers) > 1:
                 collect()
@@ -154,7 +171,10 @@ def main():
             if len(pending) == depth:
                 finish()
             slot = launches % depth
-            ctx.msm_dev_batch_begin(slot, ptrs[:m], hi - lo, part=part, parts=parts)
+            if one_proc:
+                ctx.msm_dev_begin(slot, ptrs[0], n)  # fans out over the shards (multi.hip)
+            else:
+                ctx.msm_dev_batch_begin(slot, ptrs[:m], hi - lo, part=part, parts=parts)
             pending.append((slot, m))
             launches += 1
             k -= m
@@ -226,12 +246,14 @@ def main():
         # per launch sequence: an MSM of more than 1.3 M points runs the kernel once per piece, and the
         # algorithmic bytes below are those of the whole launch
         n_launches = max(prof_steps // batch, 1)
+        if one_proc:
+            n_launches *= len(devices)  # every shard runs its own launch sequence per MSM: the figures below are per shard launch
         kern_s = acc_ms / n_launches * 1e-3
         ovl_ms, ovl_cnt = prof.get(dom, (0.0, 0))
         ovl_cnt = n_launches if ovl_cnt else 0
         # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
         # index block or their 1/parts window share on this rank)
-        alg_bytes = batch * (96 * (hi - lo) // parts + 64)
+        alg_bytes = batch * (96 * (hi - lo) // parts + 64) if not one_proc else 96 * (n // len(devices)) + 64
         # HBM-side bytes per launch: PMC counters need a rocprofv3 --pmc pass of their own (tools/evidence.sh), they cannot be
         # read inside this run -- the figure is STATIC, taken from the committed pass named in traffic_source
         traffic, traffic_source = None, None
@@ -249,23 +271,26 @@ def main():
         # blocks of 2^17 .. 2^19 points), 16 for window shards of the general 16-window plan
         plan_w = None
         if args.log_n >= 20:
-            plan_w = 16 if window_mode else (13 if hi - lo >= (1 << 20) else 15 if hi - lo >= (1 << 17) else None)
+            shard_pts = (hi - lo) if not one_proc else n // len(devices)
+            plan_w = 16 if window_mode else (13 if shard_pts >= (1 << 20) else 15 if shard_pts >= (1 << 17) else None)
         valu = None
         if plan_w and kern_s > 0:
-            wave_mads = batch * (hi - lo) * plan_w / parts * 1143 / 64
+            wave_mads = batch * shard_pts * plan_w / parts * 1143 / 64
             peak = props.multi_processor_count * 4 * 2.4e9 / 5.26  # 2.40 GHz engine clock (the microbenchmark's reading)
             valu = {"unit": "v_mad_u64_u32 wave-instr/s", "achieved": wave_mads / kern_s, "peak": peak, "frac": wave_mads / kern_s / peak}
         result = {
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
-            "value": args.steps / dt, "unit": "MSM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": args.steps / dt, "unit": "MSM/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "timed_region": {"repetitions": len(reps), "reported": "median", "seconds_each": [round(x, 6) for x in reps[:32]]},
             "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
-                       "sharding": "single GPU" if world == 1 else
+                       "sharding": ("one process, multi-device context: %d index-block shards on devices %s, partial points added on the host "
+                                    "(no collective)" % (len(devices), devices)) if one_proc and args.gpus > 1 else "single GPU" if world == 1 else
                                    ("Pippenger windows split over the ranks (key + scalars replicated), %s all-gather of 96 B partials" % coll_name if window_mode
                                     else "block index shard per rank + %s all-gather of 96 B partials" % coll_name),
-                       "collective_backend": backend_name, "world_size": world_reported, "distinct_gpus": distinct_gpus,
+                       "collective_backend": backend_name, "world_size": world_reported,
+                       "distinct_gpus": len(set(devices)) if one_proc else distinct_gpus,
                        "msms_per_launch": batch, "launches_in_flight": args.depth,
                        "window_bits": "a rank's block of >= 2^20 points: 20 with fixed-base tables over the context's key (13 windows, one set "
                                       "of 2^19 buckets); index blocks of 2^17..2^19 points: 17 (15 windows, 2^16 buckets per MSM of a batch); "
@@ -284,7 +309,14 @@ def main():
             "hbm_roofline_frac_whole_msm": (args.steps / dt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
         }
 
-    if world == 1:
+    if one_proc and args.gpus > 1:
+        # cross-check: the same MSM on a plain one-device context
+        full = h._lib.Context(urs_n=n, first_index=2, device=gpu)
+        ok = full.msm_dev(ptrs[0], n).tolist() == outs[0].tolist()
+        full.close()
+        result["sharded_equals_single_gpu"] = ok
+        assert ok, "multi-device MSM differs from the single-GPU MSM"
+    elif world == 1:
         # bit-exactness in the same run + CPU baseline (oracle = single-thread port of the arkworks path)
         gs = ctx.read_bases()
         cpu_model = "unknown"
@@ -459,7 +491,8 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     ctx.close()
     if world > 1 or force_dist:
         dist.destroy_process_group()

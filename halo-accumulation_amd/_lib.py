@@ -42,6 +42,9 @@ _SIGS = {
     "halo_ctx_create": (C.c_int, [C.c_int, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_create_urs": (C.c_int, [C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_create_urs_strided": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_create_urs_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "halo_ctx_devices": (C.c_int, [C.c_void_p]),
     "halo_ctx_destroy": (None, [C.c_void_p]),
     "halo_ctx_size": (C.c_size_t, [C.c_void_p]),
     "halo_ctx_read_bases": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p]),
@@ -177,10 +180,22 @@ def check(rc: int) -> None:
 class Context:
     """A commitment key resident on one GPU (consts.rs: N, GS)."""
 
-    def __init__(self, bases=None, *, urs_n: int | None = None, first_index: int = 2, stride: int = 1, device: int = 0):
+    def __init__(self, bases=None, *, urs_n: int | None = None, first_index: int = 2, stride: int = 1, device: int = 0, devices=None):
+        """devices=[d0, d1, ...]: a multi-device context (halo_ctx_create_multi): full context on d0, one index-block shard per entry"""
         lib = load()
         h = C.c_void_p()
-        if bases is not None:
+        if devices is not None:
+            assert stride == 1, "multi-device contexts hold index blocks"
+            if len(devices) == 0:
+                raise HaloError("ctx_create_multi: 1..64 device ids")
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            device = int(devices[0])
+            if bases is not None:
+                bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+                check(lib.halo_ctx_create_multi(devs, len(devices), ptr(bases), bases.shape[0], C.byref(h)))
+            else:
+                check(lib.halo_ctx_create_urs_multi(devs, len(devices), first_index, int(urs_n), C.byref(h)))
+        elif bases is not None:
             bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
             check(lib.halo_ctx_create(device, ptr(bases), bases.shape[0], C.byref(h)))
         elif stride != 1:
@@ -211,6 +226,10 @@ class Context:
     @property
     def size(self) -> int:
         return self.lib.halo_ctx_size(self.h)
+
+    @property
+    def n_devices(self) -> int:
+        return self.lib.halo_ctx_devices(self.h)
 
     def read_bases(self, off=0, n=None):
         n = self.size - off if n is None else n

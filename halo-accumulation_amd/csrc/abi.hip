@@ -259,8 +259,37 @@ int halo_ctx_create_urs_strided(int device, uint64_t first_index, uint64_t strid
     return HALO_OK;
 }
 
+static int ctx_devices_ok(const int *devices, int n_dev) {
+    int count = 0;
+    if (!devices || n_dev < 1 || n_dev > 64) { set_error("ctx_create_multi: 1..64 device ids"); return HALO_E_ARG; }
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device available: this library has no CPU fallback"); return HALO_E_DEVICE; }
+    for (int k = 0; k < n_dev; ++k)
+        if (devices[k] < 0 || devices[k] >= count) { set_error("ctx_create_multi: device index out of range"); return HALO_E_ARG; }
+    return HALO_OK;
+}
+int halo_ctx_create_multi(const int *devices, int n_dev, const uint64_t *bases_affine, size_t n, halo_ctx **out) {
+    int rc = ctx_devices_ok(devices, n_dev);
+    if (rc) return rc;
+    rc = halo_ctx_create(devices[0], bases_affine, n, out);
+    if (rc || n_dev == 1) return rc;
+    rc = multi_attach_shards(*out, devices, n_dev, bases_affine, 0);
+    if (rc) { halo_ctx_destroy(*out); *out = nullptr; }
+    return rc;
+}
+int halo_ctx_create_urs_multi(const int *devices, int n_dev, uint64_t first_index, size_t n, halo_ctx **out) {
+    int rc = ctx_devices_ok(devices, n_dev);
+    if (rc) return rc;
+    rc = halo_ctx_create_urs(devices[0], first_index, n, out);
+    if (rc || n_dev == 1) return rc;
+    rc = multi_attach_shards(*out, devices, n_dev, nullptr, first_index);
+    if (rc) { halo_ctx_destroy(*out); *out = nullptr; }
+    return rc;
+}
+int halo_ctx_devices(const halo_ctx *ctx) { return ctx ? (ctx->shards.empty() ? 1 : (int)ctx->shards.size()) : 0; }
+
 void halo_ctx_destroy(halo_ctx *ctx) {
     if (!ctx) return;
+    multi_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     for (auto st : ctx->streams) if (st) (void)hipStreamSynchronize(st);
     ctx->prof.collect();
@@ -315,6 +344,7 @@ int halo_msm_dev(halo_ctx *ctx, size_t off, size_t n, const void *d_scalars, int
 int halo_msm_dev_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int mont) {
     HALO_CTX(ctx);
     if (off + n > ctx->n || (n && !d_scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    if (!ctx->shards.empty()) return multi_begin(ctx, slot, off, n, nullptr, static_cast<const uint64_t *>(d_scalars), mont != 0);
     return msm_enqueue(ctx, slot, ctx->d_bases + 32 * off, static_cast<const uint64_t *>(d_scalars), mont != 0, n);
 }
 int halo_msm_dev_begin_part(halo_ctx *ctx, int slot, size_t off, size_t n, const void *d_scalars, int mont, int part, int parts) {
@@ -331,7 +361,7 @@ int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
     HALO_CTX(ctx);
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
     host::Point r;
-    int rc = msm_finish(ctx, slot, &r);
+    int rc = (!ctx->shards.empty() && slot >= 0 && slot < HALO_SLOTS && ctx->fan[slot].active) ? multi_end(ctx, slot, &r) : msm_finish(ctx, slot, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -364,7 +394,8 @@ int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out)
 
 // scalars in host memory: copied on the slot's own stream right in front of the launch sequence (no host round trip in
 // between), into a per-slot device buffer so that launches on different slots overlap with each other's copies
-static int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont) {
+} // extern "C"
+int halo::msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont) {
     if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
     if (off + n > ctx->n || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     if (ctx->wss[slot].in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
@@ -375,16 +406,20 @@ static int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const u
     if (n) HALO_HIP(hipMemcpyAsync(ctx->d_slot_scalars[slot], scalars, n * 32, hipMemcpyHostToDevice, ctx->streams[slot]));
     return msm_enqueue(ctx, slot, ctx->d_bases + 32 * off, ctx->d_slot_scalars[slot], mont != 0, n);
 }
+extern "C" {
 int halo_msm_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont) {
     HALO_CTX(ctx);
+    if (!ctx->shards.empty()) {
+        if (off + n > ctx->n || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+        return multi_begin(ctx, slot, off, n, scalars, nullptr, mont != 0);
+    }
     return msm_host_begin(ctx, slot, off, n, scalars, mont);
 }
 int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out[12]) { return halo_msm_dev_end(ctx, slot, out); }
 
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int mont, uint64_t out[12]) {
-    HALO_CTX(ctx);
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
-    int rc = msm_host_begin(ctx, 0, off, n, scalars, mont);
+    int rc = halo_msm_begin(ctx, 0, off, n, scalars, mont);
     if (rc) return rc;
     return halo_msm_dev_end(ctx, 0, out);
 }
@@ -830,27 +865,49 @@ void halo_ipa_destroy(halo_ipa *st) {
 size_t halo_ipa_len(const halo_ipa *st) { return st ? st->m : 0; }
 
 // ------------------------------------------------------------------ measurement hooks
-int halo_prof_enable(halo_ctx *ctx, int on) {
-    HALO_CTX(ctx);
+// (a multi-device context: the shards profile too, and count/get show the sums over parent and shards per kernel name)
+static int prof_enable_one(halo_ctx *ctx, int on, bool reset) {
+    HALO_HIP(hipSetDevice(ctx->device));
     for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
     ctx->prof.collect();
-    ctx->prof.on = on != 0;
-    ctx->prof.dominant_only = on == 2;
+    if (reset) {
+        for (auto &e : ctx->prof.entries) { e.total_ms = 0; e.launches = 0; }
+    } else {
+        ctx->prof.on = on != 0;
+        ctx->prof.dominant_only = on == 2;
+    }
     return HALO_OK;
+}
+static void prof_merge(halo_ctx *ctx) {
+    ctx->prof_merged = ctx->prof.entries;
+    for (halo_ctx *s : ctx->shards)
+        for (const ProfEntry &e : s->prof.entries) {
+            bool found = false;
+            for (ProfEntry &m : ctx->prof_merged)
+                if (std::strcmp(m.name, e.name) == 0) { m.total_ms += e.total_ms; m.launches += e.launches; found = true; break; }
+            if (!found) ctx->prof_merged.push_back(e);
+        }
+}
+int halo_prof_enable(halo_ctx *ctx, int on) {
+    HALO_CTX(ctx);
+    for (halo_ctx *s : ctx->shards) { int rc = prof_enable_one(s, on, false); if (rc) return rc; }
+    return prof_enable_one(ctx, on, false);
 }
 int halo_prof_reset(halo_ctx *ctx) {
     HALO_CTX(ctx);
-    for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
-    ctx->prof.collect();
-    for (auto &e : ctx->prof.entries) { e.total_ms = 0; e.launches = 0; }
-    return HALO_OK;
+    for (halo_ctx *s : ctx->shards) { int rc = prof_enable_one(s, 0, true); if (rc) return rc; }
+    return prof_enable_one(ctx, 0, true);
 }
-int halo_prof_count(halo_ctx *ctx) { return ctx ? (int)ctx->prof.entries.size() : 0; }
+int halo_prof_count(halo_ctx *ctx) {
+    if (!ctx) return 0;
+    prof_merge(ctx);
+    return (int)ctx->prof_merged.size();
+}
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches) {
-    if (!ctx || i < 0 || i >= (int)ctx->prof.entries.size()) { set_error("prof_get: index"); return HALO_E_ARG; }
-    if (name) *name = ctx->prof.entries[i].name;
-    if (total_ms) *total_ms = ctx->prof.entries[i].total_ms;
-    if (launches) *launches = ctx->prof.entries[i].launches;
+    if (!ctx || i < 0 || i >= (int)ctx->prof_merged.size()) { set_error("prof_get: index (call halo_prof_count first)"); return HALO_E_ARG; }
+    if (name) *name = ctx->prof_merged[i].name;
+    if (total_ms) *total_ms = ctx->prof_merged[i].total_ms;
+    if (launches) *launches = ctx->prof_merged[i].launches;
     return HALO_OK;
 }
 int halo_bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps) {

@@ -223,6 +223,7 @@ struct halo_ctx {
     uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.hpp AffN)
     halo::MsmWorkspace wss[HALO_SLOTS];        // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
+    std::vector<halo::ProfEntry> prof_merged;  // what halo_prof_count / _get show: this context's entries plus its shards'
     int window_bits = 0;
     int reduce_span = 0;                   // buckets per lane in k_msm_reduce1 (0 = automatic)
     int sort_two_level = -1;               // two-level sort: -1 automatic (n >= 2^17), 0 never, 1 whenever the shape allows
@@ -248,6 +249,12 @@ struct halo_ctx {
     halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker)
     IpaBuffers ipa_bufs;          // reused by every halo_ipa of this context (one at a time; a second one allocates its own)
     uint64_t alloc_epoch = 0;     // bumped whenever this context allocates or frees device memory (see msm.hip, launch graphs)
+    // multi-device contexts (multi.hip): one shard context per device over its index block of the key; MSMs over the key fan out
+    std::vector<halo_ctx *> shards;
+    std::vector<size_t> shard_lo;  // shards.size() + 1 block boundaries
+    halo_ctx *parent = nullptr;    // set on a shard
+    struct Fan { bool active = false; std::vector<char> used; };
+    Fan fan[HALO_SLOTS];           // which shards hold a stretch of the MSM in flight on each slot
 };
 
 struct halo_ipa {
@@ -302,6 +309,15 @@ int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t 
 int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+
+// ---- multi.hip: MSMs over the key of a multi-device context, cut along the shards' blocks
+int multi_attach_shards(halo_ctx *ctx, const int *devices, int n_dev, const uint64_t *bases_affine, uint64_t first_index);
+void multi_destroy(halo_ctx *ctx);
+bool multi_takes(const halo_ctx *ctx, const uint32_t *d_bases, size_t n);  // a stretch of the parent's own key?
+int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *host_scalars, const uint64_t *dev_scalars, bool mont);
+int multi_end(halo_ctx *ctx, int slot, host::Point *out);
+int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, bool mont, host::Point *out);
+int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
 int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain);

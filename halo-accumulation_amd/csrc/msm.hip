@@ -1469,6 +1469,9 @@ void msm_workspace_free(halo_ctx *ctx) {
 
 // ------------------------------------------------------------------------------ driver
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool mont, size_t n, host::Point *out) {
+    // a multi-device context: a large MSM over its own key goes to the shards (multi.hip); short ones are not worth the fan-out
+    if (n >= ((size_t)1 << 16) && multi_takes(ctx, d_bases, n))
+        return multi_run(ctx, (size_t)(d_bases - ctx->d_bases) / AFF_STRIDE, n, d_scalars, mont, out);
     int rc = msm_enqueue(ctx, 0, d_bases, d_scalars, mont, n);
     if (rc) return rc;
     return msm_finish(ctx, 0, out);

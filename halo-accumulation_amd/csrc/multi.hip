@@ -1,0 +1,165 @@
+// Multi-device contexts ("halo_ctx_create(device_ids[], n_dev, ...) uploads (and shards) bases once";
+// 8e: an MSM is a sum over independent index terms).  One process drives several GPUs:
+//
+//   * the handle the caller gets is a full context on devices[0] over the whole key -- every entry point of the
+//     library works on it unchanged (IPA state, pcdl / acc level, h(X), ...);
+//   * it owns one SHARD context per device over that device's index block of the key (block k = [k N / P, (k+1) N / P),
+//     multiples of 4; each shard derives or receives only its block and builds its own fixed-base table on first use);
+//   * an MSM over GS[off, off + n) -- halo_msm, halo_msm_dev, the begin/end halves and the library's own synchronous
+//     MSMs over the key (commit, check, h_commit) -- is cut along the block boundaries, every shard enqueues its stretch
+//     on its own device and stream, the shards' window sums are combined by their helper threads in parallel and the
+//     P partial points are added on the host in block order (halo_point_sum's rule): bit-identical to the one-device
+//     result, which is a normalised point.  Device-resident scalars are read in place by the shard on the same device
+//     and copied peer-to-peer (xGMI) for the others; host scalars go straight to each device over its own PCIe link.
+//
+// There is no collective here: one process owns all partials.  Ranks of a torch.distributed job each hold a plain
+// context and all-gather 96 bytes instead (halo-accumulation_amd/sharded.py).
+#include <algorithm>
+
+#include "curve.hpp"
+#include "internal.hpp"
+
+namespace halo {
+
+static size_t block_lo(size_t N, int P, int k) {
+    if (k >= P) return N;
+    size_t lo = (size_t)((unsigned __int128)N * (unsigned)k / (unsigned)P);
+    return lo / 4 * 4;  // (vector loads of digits want multiples of 4)
+}
+
+void multi_destroy(halo_ctx *ctx) {
+    for (halo_ctx *s : ctx->shards) halo_ctx_destroy(s);
+    ctx->shards.clear();
+    ctx->shard_lo.clear();
+}
+
+// shards over the blocks of the parent's key: derived on their own device (URS rule) or copied from the host array
+int multi_attach_shards(halo_ctx *ctx, const int *devices, int n_dev, const uint64_t *bases_affine, uint64_t first_index) {
+    size_t N = ctx->n;
+    ctx->shard_lo.resize((size_t)n_dev + 1);
+    for (int k = 0; k <= n_dev; ++k) ctx->shard_lo[k] = block_lo(N, n_dev, k);
+    for (int k = 0; k < n_dev; ++k) {
+        size_t lo = ctx->shard_lo[k], len = ctx->shard_lo[k + 1] - lo;
+        halo_ctx *s = nullptr;
+        int rc = bases_affine ? halo_ctx_create(devices[k], bases_affine + 8 * lo, len, &s) : halo_ctx_create_urs(devices[k], first_index + lo, len, &s);
+        if (rc) { multi_destroy(ctx); return rc; }
+        s->parent = ctx;
+        ctx->shards.push_back(s);
+        if (devices[k] != ctx->device) {  // direct peer copies of device-resident scalars (xGMI); without it HIP stages through the host
+            (void)hipSetDevice(devices[k]);
+            (void)hipDeviceEnablePeerAccess(ctx->device, 0);
+            (void)hipSetDevice(ctx->device);
+            (void)hipDeviceEnablePeerAccess(devices[k], 0);
+            (void)hipGetLastError();  // "already enabled" is fine
+        }
+    }
+    (void)hipSetDevice(ctx->device);
+    return HALO_OK;
+}
+
+bool multi_takes(const halo_ctx *ctx, const uint32_t *d_bases, size_t n) {
+    return !ctx->shards.empty() && d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
+}
+
+static int device_of(const void *p, int fallback) {
+    hipPointerAttribute_t a;
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess) return a.device;
+    (void)hipGetLastError();
+    return fallback;
+}
+
+// Enqueue the stretches of GS[off, off + n) on the shards' slot `slot`.  Exactly one of host_scalars / dev_scalars is set.
+int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *host_scalars, const uint64_t *dev_scalars, bool mont) {
+    if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
+    halo_ctx::Fan &fan = ctx->fan[slot];
+    if (fan.active) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    const int P = (int)ctx->shards.size();
+    fan.used.assign((size_t)P, 0);
+    int src_dev = dev_scalars ? device_of(dev_scalars, ctx->device) : -1;
+    int rc = HALO_OK;
+    std::vector<int> rcs((size_t)P, HALO_OK);
+    std::vector<std::string> errs((size_t)P);
+    for (int k = 0; k < P && !rc; ++k) {
+        size_t lo = ctx->shard_lo[k], hi = ctx->shard_lo[k + 1];
+        size_t a = std::max(off, lo), b = std::min(off + n, hi);
+        if (a >= b) continue;
+        halo_ctx *s = ctx->shards[k];
+        fan.used[k] = 1;
+        if (host_scalars) {
+            // every device has its own PCIe link: the copies run in parallel, each issued by its shard's helper thread
+            const uint64_t *src = host_scalars + 4 * (a - off);
+            s->worker.submit([s, slot, a, b, lo, src, mont, &rcs, &errs, k] {
+                (void)hipSetDevice(s->device);
+                rcs[k] = msm_host_begin(s, slot, a - lo, b - a, src, mont ? 1 : 0);
+                if (rcs[k]) errs[k] = halo_last_error();
+            });
+            continue;
+        }
+        HALO_HIP(hipSetDevice(s->device));
+        const uint64_t *src = dev_scalars + 4 * (a - off);
+        if (src_dev != s->device) {  // the scalars live on another GPU: peer copy on this shard's stream, in front of its launches
+            if (!s->d_slot_scalars[slot]) {
+                alloc_epoch_bump(s);
+                HALO_HIP(hipMalloc(&s->d_slot_scalars[slot], (s->n < 64 ? 64 : s->n) * 32));
+            }
+            HALO_HIP(hipMemcpyPeerAsync(s->d_slot_scalars[slot], s->device, src, src_dev, (b - a) * 32, s->streams[slot]));
+            src = s->d_slot_scalars[slot];
+        } else {
+            // same device, another stream: the shard's launches must see what the caller's stream has written
+            // (the caller synchronised before handing the pointer over, as for halo_msm_dev on a plain context)
+        }
+        rc = msm_enqueue(s, slot, s->d_bases + 32 * (a - lo), src, mont, b - a);
+    }
+    if (host_scalars)
+        for (int k = 0; k < P; ++k)
+            if (fan.used[k]) {
+                ctx->shards[k]->worker.wait();
+                if (rcs[k] && !rc) { rc = rcs[k]; set_error(errs[k]); }
+            }
+    (void)hipSetDevice(ctx->device);
+    fan.active = true;  // (also after a failure: multi_end drains whatever was enqueued)
+    if (rc) { host::Point dummy; std::string keep = halo_last_error(); (void)multi_end(ctx, slot, &dummy); set_error(keep); }
+    return rc;
+}
+
+// Wait for the shards, combine their window sums (each on its own helper thread), add the partials in block order.
+int multi_end(halo_ctx *ctx, int slot, host::Point *out) {
+    if (slot < 0 || slot >= HALO_SLOTS || !ctx->fan[slot].active) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
+    halo_ctx::Fan &fan = ctx->fan[slot];
+    const int P = (int)ctx->shards.size();
+    std::vector<host::Point> part((size_t)P, host::Point::infinity());
+    std::vector<int> rcs((size_t)P, HALO_OK);
+    std::vector<std::string> errs((size_t)P);
+    for (int k = 0; k < P; ++k) {
+        if (!fan.used[k]) continue;
+        halo_ctx *s = ctx->shards[k];
+        if (!s->wss[slot].in_flight) { fan.used[k] = 0; continue; }  // (its enqueue failed)
+        s->worker.submit([s, slot, k, &part, &rcs, &errs] {
+            (void)hipSetDevice(s->device);
+            rcs[k] = msm_finish(s, slot, &part[k]);
+            if (rcs[k]) errs[k] = halo_last_error();
+        });
+    }
+    int rc = HALO_OK;
+    host::Point acc = host::Point::infinity();
+    for (int k = 0; k < P; ++k) {
+        if (!fan.used[k]) continue;
+        ctx->shards[k]->worker.wait();
+        if (rcs[k] && !rc) { rc = rcs[k]; set_error(errs[k]); }
+        acc = acc + part[k];  // block order 0 .. P-1
+    }
+    fan.active = false;
+    (void)hipSetDevice(ctx->device);
+    *out = acc;
+    return rc;
+}
+
+int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, bool mont, host::Point *out) {
+    // the library's own synchronous MSMs have just written their scalars on the parent's stream
+    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = multi_begin(ctx, 0, off, n, nullptr, dev_scalars, mont);
+    if (rc) return rc;
+    return multi_end(ctx, 0, out);
+}
+
+}  // namespace halo

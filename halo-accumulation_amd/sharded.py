@@ -47,6 +47,7 @@ class ShardedMsm:
         self.device = device if device is not None else torch.device("cpu")
         self._send = torch.zeros(12, dtype=torch.int64, device=self.device)
         self._recv = torch.zeros(self.world * 12, dtype=torch.int64, device=self.device)
+        self._rings = {}  # batch size -> ring of (pinned host, device send, device recv) buffers for gather_start
 
     def gather_batch(self, parts):
         """All-gather k local partials (list of (12,) arrays) with ONE collective and combine each:
@@ -62,11 +63,24 @@ class ShardedMsm:
         local = np.ascontiguousarray(np.stack(parts), dtype=np.uint64)
         if self.world == 1 and not self.always_collective:
             return (k, local, None, None)
-        torch = self.torch
-        send = torch.from_numpy(local.view(np.int64).reshape(-1))
-        if self.device.type != "cpu":
-            send = send.pin_memory().to(self.device, non_blocking=True)
-        recv = torch.empty(self.world * k * 12, dtype=torch.int64, device=self.device)
+        # staging buffers are allocated ONCE per batch size (a ring of four sets: the handle of one launch is collected
+        # after the next launch has been issued) -- no pinned allocation, no device allocation per launch
+        ring = self._rings.setdefault(k, {"next": 0, "sets": []})
+        if len(ring["sets"]) < 4:
+            torch = self.torch
+            pinned = torch.empty(k * 12, dtype=torch.int64)
+            if self.device.type != "cpu":
+                pinned = pinned.pin_memory()
+            ring["sets"].append((pinned,
+                                 pinned if self.device.type == "cpu" else torch.empty(k * 12, dtype=torch.int64, device=self.device),
+                                 torch.empty(self.world * k * 12, dtype=torch.int64, device=self.device)))
+            pinned, send, recv = ring["sets"][-1]
+        else:
+            pinned, send, recv = ring["sets"][ring["next"] % 4]
+        ring["next"] += 1
+        pinned.numpy()[:] = local.view(np.int64).reshape(-1)
+        if send is not pinned:
+            send.copy_(pinned, non_blocking=True)
         work = self.dist.all_gather_into_tensor(recv, send, async_op=True)
         return (k, send, recv, work)
 

@@ -19,8 +19,8 @@
  * 307-310,339; acc.rs:152-155,169,237-240).
  *
  * Ownership: inputs are borrowed for the call; outputs go to caller buffers; only ctx / ipa
- * handles are library-owned.  A ctx is bound to one HIP device and one stream: calls on the
- * same ctx must not overlap; different ctxs are independent.  No global init.
+ * handles are library-owned.  A ctx is bound to one HIP device (halo_ctx_create_multi: one per shard) and its streams:
+ * calls on the same ctx must not overlap; different ctxs are independent.  No global init.
  * There is NO CPU fallback: without a gfx950 device every compute entry point fails with
  * HALO_E_DEVICE.
  */
@@ -53,6 +53,17 @@ int halo_ctx_create(int device, const uint64_t *bases_affine, size_t n, halo_ctx
 int halo_ctx_create_urs(int device, uint64_t first_index, size_t n, halo_ctx **out);
 /* same with G_j = hash(first_index + j * stride): a rank's cyclic shard of the key (stride = world size) */
 int halo_ctx_create_urs_strided(int device, uint64_t first_index, uint64_t stride, size_t n, halo_ctx **out);
+/* Multi-device contexts (one process, n_dev GPUs of one node; a device id may repeat).  The handle is a full context on
+ * devices[0] over the whole key -- every entry point works on it -- that also owns one shard context per device over that
+ * device's index block of the key (block k = [k n / n_dev, (k + 1) n / n_dev), derived or uploaded once).  halo_msm,
+ * halo_msm_dev, the begin/end halves of both and the library's own MSMs over the key (commit, check, h_commit) of at least
+ * 2^16 points are cut along the block boundaries: each shard runs its stretch on its own device and stream, the partial
+ * points are added on the host in block order -- the same normalised point as on one device.  Device-resident scalars
+ * are read in place on their own GPU and copied peer-to-peer (xGMI) to the others; host scalars go to each device over its
+ * own PCIe link.  The window-shard and batch forms (halo_msm_dev_begin_part, halo_msm_dev_batch_*) stay on devices[0]. */
+int halo_ctx_create_multi(const int *devices, int n_dev, const uint64_t *bases_affine, size_t n, halo_ctx **out);
+int halo_ctx_create_urs_multi(const int *devices, int n_dev, uint64_t first_index, size_t n, halo_ctx **out);
+int halo_ctx_devices(const halo_ctx *ctx); /* shards of a multi-device context, 1 for a plain one */
 void halo_ctx_destroy(halo_ctx *ctx);
 size_t halo_ctx_size(const halo_ctx *ctx);
 /* copy bases [off, off+n) back to the host (n x 8 limbs) */
