@@ -17,6 +17,17 @@ python tools/trace_timeline.py $(find $OUT/prof_open -name "*kernel_trace.csv" |
 step pmc_fetch; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_fetch.log 2>&1 || exit 1
 step pmc_write; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_write.log 2>&1 || exit 1
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json || exit 1
+# the bandwidth-side Fr kernels alone (K4-K9): steady-state durations and HBM-side bytes, each launch back to back
+step fr_trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fr_trace -- python3 tools/fr_kernels.py 20 20 > $OUT/fr_trace.log 2>&1 || exit 1
+step fr_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fr_fetch -- python3 tools/fr_kernels.py 20 6 > $OUT/fr_fetch.log 2>&1 || exit 1
+step fr_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/fr_write -- python3 tools/fr_kernels.py 20 6 > $OUT/fr_write.log 2>&1 || exit 1
+python tools/pmc_summary.py $OUT/fr_fetch $OUT/fr_write "python3 tools/fr_kernels.py 20 6" > $OUT/pmc_fr.json || exit 1
+python tools/fr_kernels.py 20 20 > $OUT/fr_kernels_events.json 2>/dev/null || exit 1
+( cd tools && ./fr29_bench > ../$OUT/fr29_bench.txt 2>&1 ) || true
+# multi-device context from ONE process (halo_ctx_create_urs_multi), the one GPU of this box standing in for every device
+for N in 2 4 8; do
+  step oneproc$N; timeout -k 10 300 python bench.py --gpus $N --one-process --devices $(python -c "print(','.join(['0']*$N))") --steps 64 --min-seconds 0.3 > $OUT/bench_oneproc$N.json 2> $OUT/bench_oneproc$N.err || exit 1
+done
 export HALO_BENCH_BACKEND=gloo
 for N in 2 4; do
   step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 2> $OUT/bench_gloo$N.err | grep '^{' > $OUT/bench_gloo$N.json || exit 1
