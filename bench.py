@@ -51,6 +51,7 @@ def main():
                     help="--gpus N from ONE process (no torch.distributed): a multi-device context (halo_ctx_create_urs_multi), one "
                          "index-block shard per GPU, partial points added on the host")
     ap.add_argument("--devices", default="", help="--one-process: comma-separated device ids (default 0..N-1; ids may repeat for a rehearsal)")
+    ap.add_argument("--host-steps", type=int, default=8, help="MSMs with the scalars in host memory (halo_msm and its begin/end halves) at N=1 (0 = skip)")
     ap.add_argument("--fr-reps", type=int, default=20, help="back-to-back launches of each bandwidth-side Fr kernel at N=1 (0 = skip)")
     ap.add_argument("--asdl-steps", type=int, default=8, help="ASDL chain steps (random_instance + prover + verifier, then one decider) at N=1 (0 = skip)")
     args = ap.parse_args()
@@ -324,38 +325,39 @@ def main():
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        # the same MSM with the scalars handed over in HOST memory (halo_msm: 32 MiB H2D per MSM at n = 2^20, pageable):
-        # the PCIe-inclusive rate; never `value`
         sc_host = np.ascontiguousarray(d_sets[0].cpu().numpy().view(np.uint64).reshape(n, 4))
-        ctx.msm(sc_host)
-        t0 = time.perf_counter()
-        for _ in range(8):
-            got_h = ctx.msm(sc_host)
-        h2d_dt = (time.perf_counter() - t0) / 8
-        assert got_h.tolist() == out.tolist()
-        # the same through the asynchronous halves (halo_msm_begin / halo_msm_end): the copy of the next MSM's scalars runs while
-        # the current MSM's kernels do
-        K, D = 16, 3
-        ctx.msm_begin(0, sc_host); ctx.msm_end(0)
-        t0 = time.perf_counter()
-        for k in range(K + D):
-            if k >= D:
-                got_p = ctx.msm_end(k % D)
-            if k < K:
-                ctx.msm_begin(k % D, sc_host)
-        pipe_dt = (time.perf_counter() - t0) / K
-        assert got_p.tolist() == out.tolist()
-        t0 = time.perf_counter()
-        for _ in range(4):
-            d_tmp = torch.from_numpy(sc_host.view(np.int64)).to(dev)
-            torch.cuda.synchronize()
-        copy_dt = (time.perf_counter() - t0) / 4
-        result["end_to_end_host_scalars"] = {"value": 1.0 / h2d_dt, "unit": "MSM/s", "ms": h2d_dt * 1e3,
-                                             "pipelined_value": 1.0 / pipe_dt, "pipelined_ms": pipe_dt * 1e3,
-                                             "h2d_copy_alone_ms": copy_dt * 1e3, "h2d_copy_GBs": sc_host.nbytes / copy_dt / 1e9,
-                                             "note": "halo_msm: %d MiB of scalars copied from pageable host memory each call, one MSM in flight (a call is "
-                                                     "the copy + the latency of one MSM); pipelined: halo_msm_begin/_end on %d slots, the next copy under the "
-                                                     "current kernels; h2d_copy_alone: the same buffer through torch, for scale" % (sc_host.nbytes >> 20, D)}
+        if args.host_steps > 0:
+            # the same MSM with the scalars handed over in HOST memory (halo_msm: 32 MiB H2D per MSM at n = 2^20, pageable):
+            # the PCIe-inclusive rate; never `value`
+            ctx.msm(sc_host)
+            t0 = time.perf_counter()
+            for _ in range(args.host_steps):
+                got_h = ctx.msm(sc_host)
+            h2d_dt = (time.perf_counter() - t0) / args.host_steps
+            assert got_h.tolist() == out.tolist()
+            # the same through the asynchronous halves (halo_msm_begin / halo_msm_end): the copy of the next MSM's scalars runs while
+            # the current MSM's kernels do
+            K, D = 16, 3
+            ctx.msm_begin(0, sc_host); ctx.msm_end(0)
+            t0 = time.perf_counter()
+            for k in range(K + D):
+                if k >= D:
+                    got_p = ctx.msm_end(k % D)
+                if k < K:
+                    ctx.msm_begin(k % D, sc_host)
+            pipe_dt = (time.perf_counter() - t0) / K
+            assert got_p.tolist() == out.tolist()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                d_tmp = torch.from_numpy(sc_host.view(np.int64)).to(dev)
+                torch.cuda.synchronize()
+            copy_dt = (time.perf_counter() - t0) / 4
+            result["end_to_end_host_scalars"] = {"value": 1.0 / h2d_dt, "unit": "MSM/s", "ms": h2d_dt * 1e3,
+                                                 "pipelined_value": 1.0 / pipe_dt, "pipelined_ms": pipe_dt * 1e3,
+                                                 "h2d_copy_alone_ms": copy_dt * 1e3, "h2d_copy_GBs": sc_host.nbytes / copy_dt / 1e9,
+                                                 "note": "halo_msm: %d MiB of scalars copied from pageable host memory each call, one MSM in flight (a call is "
+                                                         "the copy + the latency of one MSM); pipelined: halo_msm_begin/_end on %d slots, the next copy under the "
+                                                         "current kernels; h2d_copy_alone: the same buffer through torch, for scale" % (sc_host.nbytes >> 20, D)}
         if args.cpu_msms > 0:
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
             sc_all = sc_host

@@ -15,7 +15,7 @@ def cp(src, name):
 def stats(d, name):
     f = glob.glob(os.path.join(ev, d, "**", "*kernel_stats.csv"), recursive=True)
     if f:
-        cp(f[0], name)
+        cp(max(f, key=os.path.getmtime), name)  # (an earlier round's merge may have left older files in the same directory)
 
 
 cp(os.path.join(ev, "bench.json"), "bench.json")
