@@ -95,20 +95,21 @@ int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *h
             });
             continue;
         }
-        HALO_HIP(hipSetDevice(s->device));
+        // (no early return in here: whatever has been enqueued on other shards is drained below if this one fails)
         const uint64_t *src = dev_scalars + 4 * (a - off);
-        if (src_dev != s->device) {  // the scalars live on another GPU: peer copy on this shard's stream, in front of its launches
+        hipError_t e = hipSetDevice(s->device);
+        const bool staged = src_dev != s->device || getenv("HALO_TEST_FORCE_PEER_COPY");  // (test hook: the copy path on a one-GPU box)
+        if (e == hipSuccess && staged) {  // the scalars live on another GPU: peer copy on this shard's stream, in front of its launches
             if (!s->d_slot_scalars[slot]) {
                 alloc_epoch_bump(s);
-                HALO_HIP(hipMalloc(&s->d_slot_scalars[slot], (s->n < 64 ? 64 : s->n) * 32));
+                e = hipMalloc(&s->d_slot_scalars[slot], (s->n < 64 ? 64 : s->n) * 32);
             }
-            HALO_HIP(hipMemcpyPeerAsync(s->d_slot_scalars[slot], s->device, src, src_dev, (b - a) * 32, s->streams[slot]));
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(s->d_slot_scalars[slot], s->device, src, src_dev, (b - a) * 32, s->streams[slot]);
             src = s->d_slot_scalars[slot];
-        } else {
-            // same device, another stream: the shard's launches must see what the caller's stream has written
-            // (the caller synchronised before handing the pointer over, as for halo_msm_dev on a plain context)
         }
-        rc = msm_enqueue(s, slot, s->d_bases + 32 * (a - lo), src, mont, b - a);
+        // (same device: the shard reads the caller's buffer in place; as for halo_msm_dev on a plain context the caller has
+        // synchronised whatever wrote it)
+        rc = e != hipSuccess ? hip_fail(e, "multi-device MSM: peer copy of the scalars") : msm_enqueue(s, slot, s->d_bases + 32 * (a - lo), src, mont, b - a);
     }
     if (host_scalars)
         for (int k = 0; k < P; ++k)

@@ -77,6 +77,30 @@ def test_multi_ctx_2_20_equals_single_context(hal, P):
         c.close()
 
 
+def test_multi_ctx_peer_copy_path(hal, monkeypatch):
+    """Device-resident scalars on a GPU other than a shard's are copied peer-to-peer into the shard's slot buffer in front of
+    its launches.  One GPU here, so the copy path is forced (HALO_TEST_FORCE_PEER_COPY): hipMemcpyPeerAsync between a
+    device and itself is a device-to-device copy; buffers, ordering and offsets are the real ones."""
+    import torch
+    n = 1 << 18
+    d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    c = hal.Context(urs_n=n, devices=[0, 0, 0, 0])
+    try:
+        c.rng_scalars_dev(0x9EE9, n, d.data_ptr())
+        torch.cuda.synchronize()
+        want = c.msm_dev(d.data_ptr(), n)
+        want_off = c.msm_dev(d.data_ptr() + 32 * 1000, n - 5000, off=3000)
+        monkeypatch.setenv("HALO_TEST_FORCE_PEER_COPY", "1")
+        for _ in range(2):
+            assert c.msm_dev(d.data_ptr(), n).tolist() == want.tolist()
+            assert c.msm_dev(d.data_ptr() + 32 * 1000, n - 5000, off=3000).tolist() == want_off.tolist()
+        for slot in range(4):
+            c.msm_dev_begin(slot, d.data_ptr(), n)
+        assert all(c.msm_dev_end(slot).tolist() == want.tolist() for slot in range(4))
+    finally:
+        c.close()
+
+
 def test_multi_ctx_2_24_equals_single_context(hal):
     """BASELINE config 5's size in one process: 8 shards of 2^21 points (each a fixed-base-table MSM in two pieces)."""
     import torch
