@@ -122,6 +122,8 @@ _SIGS = {
     "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_table_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_fold_table": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_ctx_info": (C.c_size_t, [C.c_void_p, C.c_int]),
     "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
@@ -392,6 +394,13 @@ class Context:
 
     def set_fold_levels(self, levels):
         check(self.lib.halo_set_fold_levels(self.h, levels))
+
+    def set_fold_table(self, mode):
+        check(self.lib.halo_set_fold_table(self.h, mode))
+
+    def info(self, what: int) -> int:
+        """0: MSM table bytes, 1: fold table bytes, 2: fold table build time in microseconds"""
+        return self.lib.halo_ctx_info(self.h, what)
 
     def set_table_mode(self, mode):
         check(self.lib.halo_set_table_mode(self.h, mode))

@@ -296,6 +296,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     ctx->worker.stop();
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     msm_workspace_free(ctx);
+    foldtab_release(ctx);
     ipa_bufs_release(ctx);
     (void)hipFree(ctx->d_bases);
     (void)hipFree(ctx->d_tmp_a);
@@ -1062,6 +1063,24 @@ int halo_set_fold_levels(halo_ctx *ctx, int levels) {
     if (!ctx || (levels != 1 && levels != 2)) { set_error("fold levels must be 1 or 2"); return HALO_E_ARG; }
     ctx->fold_levels = levels;
     return HALO_OK;
+}
+int halo_set_fold_table(halo_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) { set_error("fold table mode must be -1 (from the second full-size open), 0 (never) or 1 (at the first)"); return HALO_E_ARG; }
+    if (mode == 0 && ctx->d_foldtab) {
+        HALO_CTX(ctx);
+        for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
+        foldtab_release(ctx);
+    }
+    ctx->fold_table_mode = mode;
+    return HALO_OK;
+}
+/* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds its build took */
+size_t halo_ctx_info(const halo_ctx *ctx, int what) {
+    if (!ctx) return 0;
+    if (what == 0) return ctx->d_table ? (size_t)ctx->tbl.W * ctx->n * 128 : 0;
+    if (what == 1) return ctx->foldtab_bytes;
+    if (what == 2) return (size_t)(ctx->foldtab_build_ms * 1e3);
+    return 0;
 }
 int halo_set_task_len(halo_ctx *ctx, int len) {
     if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }

@@ -235,6 +235,11 @@ struct halo_ctx {
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 14;  // key size at which the IPA stops folding G (0/1 = never)
     bool batch_verify = true;              // succinct checks of >= 64 instances in two device launches (else a host thread pool)
+    int fold_table_mode = -1;              // comb table for the first fold of an open (foldtab.hip): -1 from the second full-size open on, 1 at once, 0 never
+    uint32_t *d_foldtab = nullptr;         // E[w][d][i - n/4] = d 16^w G_i, 64-byte affine entries
+    size_t foldtab_bytes = 0;
+    double foldtab_build_ms = 0;
+    int foldtab_opens = 0;                 // full-size opens seen while the table did not exist
     int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -309,6 +314,10 @@ int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t 
 int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+
+// ---- foldtab.hip: the first two-level fold of an open from a comb table over the context's key
+int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]);  // 1 = done, 0 = not applicable
+void foldtab_release(halo_ctx *ctx);
 
 // ---- multi.hip: MSMs over the key of a multi-device context, cut along the shards' blocks
 int multi_attach_shards(halo_ctx *ctx, const int *devices, int n_dev, const uint64_t *bases_affine, uint64_t first_index);

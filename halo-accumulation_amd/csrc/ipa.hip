@@ -656,6 +656,11 @@ int ipa_fold_points(halo_ctx *ctx, uint32_t *d_G, size_t m, const host::Fr &xi_m
 // dst[j] <- src[j] + s[0] src[j+m] + s[1] src[j+2m] + s[2] src[j+3m], j < m (dst may be src)
 int ipa_fold_points4(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]) {
     if (m == 0) return HALO_OK;
+    {   // the fold from the context's own (constant) key: a comb table replaces the doubling chain (foldtab.hip)
+        int done = fold_points4_tab(ctx, d_src, d_dst, m, s);
+        if (done < 0) return done;
+        if (done) return HALO_OK;
+    }
     GlvArg3 a;
     a.ndigits = 0;
     for (int t = 0; t < 3; ++t) {

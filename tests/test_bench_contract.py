@@ -34,6 +34,7 @@ def test_bench_emits_contract_json():
     assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0
     assert r["bit_exact_vs_cpu"] is True
     assert r["pcdl_open_check"]["value"] > 0 and r["pcdl_open_check"]["end_to_end_host_polynomial_ms"] > 0
+    assert "fold_table_bytes" in r["pcdl_open_check"]
     assert r["timed_region"]["repetitions"] >= 1 and r["timed_region"]["reported"] == "median"
     assert r["end_to_end_host_scalars"]["value"] > 0 and r["asdl_chain"]["all_accepted"] is True
     assert "cpu_model" in cb and r["cpu_baseline_all_cores"]["cores"] >= 1

@@ -468,6 +468,77 @@ def test_open_2_19_matches_oracle_fixture(hal):
         c.close()
 
 
+@pytest.mark.parametrize("lg", [6, 9, 12, 15])
+def test_open_with_fold_table_matches_oracle(hal, lg):
+    """The first fold of an open from the comb table over the context's key (foldtab.hip: 64 entries added up per scalar, no
+    doubling chain) against the CPU restatement's double-and-add fold (pcdl.rs:216-224): proofs equal the oracle's and the
+    generic kernel's, hiding and not; built on demand, released on request."""
+    from halo_accumulation_amd import pcdl
+    n, d = 1 << lg, (1 << lg) - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        if lg <= 14:
+            c.set_ipa_switch(4)  # (keys up to 2^14 points are not folded at all by default: fold them, two rounds at a time)
+        gs = c.read_bases()
+        ppl = orc.make_pp(gs) if lg <= 12 else None  # (the oracle's open is seconds per proof above 2^12)
+        coeffs, s = orc.rng_scalars(0xF01D + lg, n - 1)
+        zw, _ = orc.rng_scalars(s, 2)
+        for hiding in (False, True):
+            w = zw[1] if hiding else None
+            C = pcdl.commit(c, coeffs, d, w)
+            c.set_fold_table(0)
+            want = pcdl.open(c, [77], coeffs, C, d, zw[0], w)
+            assert c.info(1) == 0
+            c.set_fold_table(1)
+            got = pcdl.open(c, [77], coeffs, C, d, zw[0], w)
+            assert c.info(1) == 512 * 64 * (n - n // 4), "the table covers the upper three quarters of the key"
+            assert got.tolist() == want.tolist()
+            assert pcdl.open(c, [77], coeffs, C, d, zw[0], w).tolist() == want.tolist()  # (table already there)
+            if ppl is not None:
+                ref, _ = orc.pcdl_open(ppl, 77, coeffs, C, d, zw[0], w)
+                assert got.tolist() == ref.tolist()
+            pcdl.check_proof(c, C, d, zw[0], c.poly_eval(coeffs, zw[0]), got)
+        # default mode: the second full-size open builds it (contexts of >= 2^18 points only: not this one)
+        c.set_fold_table(0)
+        c.set_fold_table(-1)
+        pcdl.open(c, [77], coeffs, C, d, zw[0], w); pcdl.open(c, [77], coeffs, C, d, zw[0], w)
+        assert c.info(1) == 0
+        # an open over a prefix of the key does not use (or build) the table
+        if lg >= 9:
+            c.set_fold_table(1)
+            d2 = n // 2 - 1
+            C2 = pcdl.commit(c, coeffs[:d2], d2)
+            p2 = pcdl.open(c, [5], coeffs[:d2], C2, d2, zw[0])
+            assert c.info(1) == 0
+            pcdl.check_proof(c, C2, d2, zw[0], c.poly_eval(coeffs[:d2], zw[0]), p2)
+    finally:
+        c.close()
+
+
+def test_open_2_19_fold_table_matches_oracle_fixture(hal):
+    """the same fixture as above with the comb table in use from the first open on"""
+    import hashlib, json, os
+    from halo_accumulation_amd import pcdl
+    with open(os.path.join(ROOT, "tests", "golden", "open_2_19.json")) as f:
+        fx = json.load(f)
+    lg = fx["lg_n"]
+    n, d = 1 << lg, (1 << lg) - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        c.set_fold_table(1)
+        coeffs, s = orc.rng_scalars(fx["coeff_seed"], fx["deg"] + 1)
+        zw, _ = orc.rng_scalars(s, 2)
+        for name in ("plain", "hiding"):
+            case = fx["cases"][name]
+            w = zw[1] if case["hiding"] else None
+            C = pcdl.commit(c, coeffs, d, w)
+            pi = pcdl.open(c, [fx["open_seed"]], coeffs, C, d, zw[0], w)
+            assert hashlib.sha256(pi.tobytes()).hexdigest() == case["proof_sha256"]
+        assert c.info(1) == 512 * 64 * (n - n // 4) and c.info(2) > 0
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ sharded open (SURVEY 8e)
 def _sharded_worker(rank, world, port, n, q):
     import os, sys

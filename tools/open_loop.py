@@ -15,6 +15,7 @@ DEV = "host" not in sys.argv[3:]  # default: the polynomial is resident in devic
 n = 1 << lg; d = n - 1
 ctx = h._lib.Context(urs_n=n)
 if os.environ.get("REDUCE_SPAN"): ctx.set_reduce_span(int(os.environ["REDUCE_SPAN"]))  # development sweep
+if os.environ.get("FOLD_TABLE"): ctx.set_fold_table(int(os.environ["FOLD_TABLE"]))     # -1 default, 0 never, 1 at the first open
 _d = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(3, n + 2, _d.data_ptr())
 _co = np.ascontiguousarray(_d.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
@@ -29,5 +30,5 @@ for k in range(K):
     t1 = time.perf_counter()
     pcdl.check_proof(ctx, C, d, z, v, pi)
     t2 = time.perf_counter()
-    print("open %.2f ms  check %.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+    print("open %.2f ms  check %.2f ms   (fold table: %.1f GB, built in %.1f ms)" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, ctx.info(1) / 1e9, ctx.info(2) / 1e3), flush=True)
 ctx.close()
