@@ -258,11 +258,11 @@ def main():
         # HBM-side bytes per launch: PMC counters need a rocprofv3 --pmc pass of their own (tools/evidence.sh), they cannot be
         # read inside this run -- the figure is STATIC, taken from the committed pass named in traffic_source
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if world == 1 and args.log_n == 20 and os.path.exists(pmc):
             pj = json.load(open(pmc))
             traffic = pj["kernels"].get(dom, {}).get("traffic_bytes_per_launch")
-            traffic_source = "static: profiles/r02_pmc_traffic.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+            traffic_source = "static: profiles/r03_pmc_traffic.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         # VALU view of the same kernel: one mixed XYZZ addition is 1143 v_mad_u64_u32 on the
         # kernel's hot path (counted in the gfx950 ISA), one per point per window; the issue peak is the measured
