@@ -1015,6 +1015,7 @@ int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
 int halo_set_graphs(halo_ctx *ctx, int on) {
     if (!ctx) { set_error("null context"); return HALO_E_ARG; }
     ctx->use_graphs = on != 0;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_graphs(sh, on);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 int halo_set_ipa_switch(halo_ctx *ctx, size_t size) {
@@ -1025,18 +1026,21 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size) {
 int halo_set_window_bits(halo_ctx *ctx, int c) {
     if (!ctx || (c != 0 && (c < 4 || c > 16))) { set_error("window bits must be 0 or in [4, 16]"); return HALO_E_ARG; }
     ctx->window_bits = c;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_window_bits(sh, c);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 
 int halo_set_reduce_span(halo_ctx *ctx, int span) {
     if (!ctx || span < 0 || span > 512 || (span & (span - 1))) { set_error("reduce span must be 0 or a power of two <= 512"); return HALO_E_ARG; }
     ctx->reduce_span = span;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_reduce_span(sh, span);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 
 int halo_set_sort_mode(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 1) { set_error("sort mode must be -1 (automatic), 0 (one level) or 1 (two levels)"); return HALO_E_ARG; }
     ctx->sort_two_level = mode;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_sort_mode(sh, mode);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 int halo_set_table_mode(halo_ctx *ctx, int mode) {
@@ -1047,11 +1051,13 @@ int halo_set_table_mode(halo_ctx *ctx, int mode) {
         if (rc) return rc;
     }
     ctx->table_mode = mode;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_table_mode(sh, mode);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 int halo_set_small_path(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
     ctx->small_path = mode;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_small_path(sh, mode);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 int halo_set_batch_verify(halo_ctx *ctx, int on) {
@@ -1085,6 +1091,7 @@ size_t halo_ctx_info(const halo_ctx *ctx, int what) {
 int halo_set_task_len(halo_ctx *ctx, int len) {
     if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }
     ctx->task_len = len;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_task_len(sh, len);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
 

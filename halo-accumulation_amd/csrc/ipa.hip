@@ -696,8 +696,9 @@ static unsigned reduce_blocks(size_t work_items) {
 
 // two elements per lane and trip, at most 512 blocks (two waves per SIMD): the lanes of a large dot product run several trips
 static unsigned dot_blocks(size_t m) {
-    size_t nb = ((m + 1) / 2 + 255) / 256;
-    if (nb > 512) nb = 512;
+    static const size_t cap_env = getenv("HALO_DOT_BLOCKS") ? (size_t)atoi(getenv("HALO_DOT_BLOCKS")) : 0;  // development override
+    size_t nb = ((m + 1) / 2 + 255) / 256, cap = cap_env ? cap_env : 512;
+    if (nb > cap) nb = cap;
     if (nb == 0) nb = 1;
     return (unsigned)nb;
 }

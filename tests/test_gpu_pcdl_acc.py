@@ -515,6 +515,26 @@ def test_open_with_fold_table_matches_oracle(hal, lg):
         c.close()
 
 
+def test_fold_table_memory_failure_falls_back(hal, monkeypatch):
+    """no memory for the comb table: one line on stderr, the generic fold kernel runs, same proof, no second attempt"""
+    from halo_accumulation_amd import pcdl
+    n, d = 1 << 15, (1 << 15) - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        coeffs, s = orc.rng_scalars(0xFA11, n - 3)
+        zw, _ = orc.rng_scalars(s, 1)
+        C = pcdl.commit(c, coeffs, d)
+        c.set_fold_table(0)
+        want = pcdl.open(c, [9], coeffs, C, d, zw[0])
+        monkeypatch.setenv("HALO_TEST_TABLE_FAIL", "1")
+        c.set_fold_table(1)
+        for _ in range(2):
+            assert pcdl.open(c, [9], coeffs, C, d, zw[0]).tolist() == want.tolist()
+        assert c.info(1) == 0
+    finally:
+        c.close()
+
+
 def test_open_2_19_fold_table_matches_oracle_fixture(hal):
     """the same fixture as above with the comb table in use from the first open on"""
     import hashlib, json, os

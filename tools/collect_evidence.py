@@ -37,3 +37,39 @@ t = os.path.join(ev, "pytest_gpu.txt")
 if os.path.exists(t):
     with open(os.path.join(prof, "%s_pytest_gpu_summary.txt" % tag), "w") as o:
         o.write(open(t).read().strip().splitlines()[-1] + "\n")
+
+# r03_pmc_open.json: join the PMC bytes of the Fr kernels with their rocprofv3 durations (tools/fr_kernels.py, launched back
+# to back) and their algorithmic bytes -> GB/s per kernel, run alone, n = 2^20
+try:
+    import csv
+    pj = os.path.join(prof, "%s_pmc_open.json" % tag)
+    st = os.path.join(prof, "%s_fr_kernels_kernel_stats.csv" % tag)
+    ev_json = os.path.join(prof, "%s_fr_kernels_events.json" % tag)
+    if os.path.exists(pj) and os.path.exists(st) and os.path.exists(ev_json):
+        d = json.load(open(pj))
+        dur = {r["Name"].split("(")[0].replace("halo::", "").replace("void ", ""): r for r in csv.DictReader(open(st))}
+        alg = {}
+        for k in json.load(open(ev_json))["kernels"]:
+            alg.setdefault(k["kernel"], []).append(k["algorithmic_bytes"])
+        out = {}
+        for name, v in d["kernels"].items():
+            base = name.replace("void ", "").split("<")[0]
+            if base not in alg:
+                continue
+            r = dur.get(name.replace("void ", ""))
+            if not r:
+                continue
+            us = float(r["AverageNs"]) / 1e3
+            a = alg[base][0] if len(alg[base]) == 1 or "<false>" in name or "<" not in name else alg[base][-1]
+            v = dict(v)
+            v.update({"rocprofv3_avg_us": us, "rocprofv3_min_us": float(r["MinNs"]) / 1e3, "rocprofv3_max_us": float(r["MaxNs"]) / 1e3,
+                      "algorithmic_bytes": a, "GBps_algorithmic": a / us / 1e3, "GBps_hbm_side": v["traffic_bytes_per_launch"] / us / 1e3,
+                      "frac_of_8TBs": a / us / 1e3 / 8000.0})
+            out[name] = v
+        d["kernels"] = out
+        d["note"] += " Durations: rocprofv3 --kernel-trace --stats of the same program with 20 launches per kernel (%s_fr_kernels_kernel_stats.csv); " \
+                     "algorithmic bytes as in DESIGN.md 4.4." % tag
+        json.dump(d, open(pj, "w"), indent=1)
+        print("   joined", os.path.basename(pj))
+except Exception as e:  # the summaries above are already in place
+    print("   (pmc_open join skipped: %s)" % e)
