@@ -3,14 +3,16 @@
 // where G is the context's own key -- a constant (consts.rs:68), like the bases of the MSM tables of msm.hip.  The generic
 // kernel multiplies each of the three points by its scalar with a shared 128-step doubling chain (Straus over GLV digit
 // strings: ~128 doublings + ~213 mixed additions, ~3240 field products per output).  With
-//     E[w][d][i] = d * 16^w * G_i   (w < 64, d = 1..8, i in [n/4, n), affine, 64 bytes each, 32 KiB per point)
-// a scalar multiple is 64 table entries added up (signed base-16 digits, no doublings at all): ~180 mixed additions per
-// output, ~2000 products -- the pass over 2^18 outputs goes from 5.3 to ~3.3 ms.  The digits depend on the challenges only,
-// i.e. they are the same for every lane of a wave: entry (w, d) of consecutive points is read by consecutive lanes, so the
-// layout [w][d][i] makes every gather a fully coalesced 4 KiB read (3 GB per pass at n = 2^20).
+//     E[w][d][i] = d * 64^w * G_i   (w < 22, d = 1..32, i in [n/4, n), affine, 64 bytes each, 44 KiB per point)
+// and the endomorphism (s = k1 + k2 lambda with |k1|, |k2| < 2^128, lambda (x, y) = (beta x, y): host_math.hpp glv_decompose)
+// a scalar multiple is 2 x 22 table entries added up (signed base-64 digits of k1 and k2; the k2 entries get their x
+// multiplied by beta), no doublings at all: ~128 mixed additions per output, ~1500 products -- the pass over 2^18 outputs
+// goes from 5.4 to ~2.6 ms.  The digits depend on the challenges only, i.e. they are the same for every lane of a wave:
+// entry (w, d) of consecutive points is read by consecutive lanes, so the layout [w][d][i] makes every gather a fully
+// coalesced 4 KiB read (2.1 GB per pass at n = 2^20).
 //
-// Cost: 25.8 GB at n = 2^20 (of 288 GB) and ~0.1 s to build (512 group operations and one share of an inversion per table
-// entry) -- forty opens' worth of savings.  So the table is built on the SECOND full-size open of a context (mode -1,
+// Cost: 35.4 GB at n = 2^20 (of 288 GB) and ~0.2 s to build (704 group operations and one share of an inversion per table
+// entry) -- seventy opens' worth of savings.  So the table is built on the SECOND full-size open of a context (mode -1,
 // default; halo_set_fold_table: 1 = at the first, 0 = never), which a prover chain (acc.rs:190-228: two opens per step)
 // reaches at once and a single open never does.  No memory, no table: the generic kernel gives the same points.
 #include "curve.hpp"
@@ -18,7 +20,7 @@
 
 namespace halo {
 
-constexpr int FT_WINDOWS = 64, FT_MULT = 8, FT_ENTRIES = FT_WINDOWS * FT_MULT;
+constexpr int FT_WINDOWS = 22, FT_BITS = 6, FT_MULT = 32, FT_ENTRIES = FT_WINDOWS * FT_MULT;  // 22 x 6 = 132 bits >= the 129 of a GLV half
 constexpr int FT_WORDS = 16;  // x | y, canonical native-form values (x 2^261 mod p) as 8 x 32-bit words each; all zero = infinity
 
 // ---- packed entries
@@ -49,10 +51,10 @@ HALO_DEV AffN ft_load(const uint32_t *p) {
     return r;  // (all-zero words = all-zero limbs = the infinity marker of AffN)
 }
 
-// ---- build: lane s of a slice takes point i = first + s.  Forward: the 512 multiples in XYZZ form, window by window
-// (P, 2P, 3P = 2P + P, 4P = 2 (2P), 5P = 4P + P, 6P = 2 (3P), 7P = 6P + P, 8P = 2 (4P); the next window starts at 2 (8P)),
-// each written to tmp[e][s] next to the running product of the ZZZ's.  One inversion per point.  Backward: 1 / ZZZ_e from
-// the running products, x = X ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2), y = Y / ZZZ, packed into E[e][i - lo].
+// ---- build: lane s of a slice takes point i = first + s.  Forward: the 704 multiples in XYZZ form, window by window
+// (d P = 2 ((d / 2) P) for even d, (d - 1) P + P for odd d; the next window starts at 2 (32 P) = 64 P), each written to
+// tmp[e][s] next to the running product of the ZZZ's.  One inversion per point.  Backward: 1 / ZZZ_e from the running
+// products, x = X ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2), y = Y / ZZZ, packed into E[e][i - lo].
 constexpr int FT_TMP_WORDS = 50;  // XYZZ (40) + running product (10)
 __global__ __launch_bounds__(256) void k_foldtab_build(const uint32_t *__restrict__ bases, uint32_t first, uint32_t count, uint32_t lo, uint32_t cnt,
                                                        uint32_t *__restrict__ tmp, uint32_t *__restrict__ tab) {
@@ -70,22 +72,15 @@ __global__ __launch_bounds__(256) void k_foldtab_build(const uint32_t *__restric
 #pragma unroll 1
     for (int w = 0; w < FT_WINDOWS; w++) {
         int e0 = w * FT_MULT;
-        emit(e0, P1);
-        XyzzN t = xyzz_dbl(P1);  // 2P
-        emit(e0 + 1, t);
-        xyzz_add(t, P1);         // 3P
-        emit(e0 + 2, t);
-        t = xyzz_dbl(xyzz_load(slot(e0 + 1)));  // 4P
-        emit(e0 + 3, t);
-        xyzz_add(t, P1);         // 5P
-        emit(e0 + 4, t);
-        t = xyzz_dbl(xyzz_load(slot(e0 + 2)));  // 6P
-        emit(e0 + 5, t);
-        xyzz_add(t, P1);         // 7P
-        emit(e0 + 6, t);
-        t = xyzz_dbl(xyzz_load(slot(e0 + 3)));  // 8P
-        emit(e0 + 7, t);
-        P1 = xyzz_dbl(t);        // 16 P: the next window's unit
+        XyzzN t = P1;
+        emit(e0, t);
+#pragma unroll 1
+        for (int d = 2; d <= FT_MULT; d++) {
+            if (d & 1) xyzz_add(t, P1);                          // (d - 1) P + P
+            else t = xyzz_dbl(xyzz_load(slot(e0 + d / 2 - 1)));  // 2 ((d / 2) P)
+            emit(e0 + d - 1, t);
+        }
+        P1 = xyzz_dbl(t);  // 64 P: the next window's unit
     }
     Fq<2> inv = fq_inv(run);
 #pragma unroll 1
@@ -105,33 +100,39 @@ __global__ __launch_bounds__(256) void k_foldtab_build(const uint32_t *__restric
     }
 }
 
-// ---- the fold: digits (signed base 16, one byte each, four per word) are kernel arguments: wave-uniform
-struct FoldDigits { uint32_t w[3][16]; };
+// ---- the fold: six digit strings (k1, k2 of the three scalars; signed base 64, one byte per digit, four per word) are
+// kernel arguments: wave-uniform
+struct FoldDigits { uint32_t w[6][6]; };
 HALO_DEV JacN fold_one_tab(const uint32_t *__restrict__ G, const uint32_t *__restrict__ tab, uint32_t j, uint32_t m, uint32_t lo, uint32_t cnt,
                            const FoldDigits &dg) {
+    constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
+    Fq<1> beta;
+#pragma unroll
+    for (int i = 0; i < 9; i++) beta.v[i] = BETA[i];
     JacN acc = jac_from_aff(aff_load(G + AFF_STRIDE * (size_t)j));
 #pragma unroll 1
-    for (int word = 0; word < 16; word++) {
-        uint32_t d1 = 0, d2 = 0, d3 = 0;
+    for (int word = 0; word < 6; word++) {
+        uint32_t d[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 16; q++) {  // (no runtime-indexed argument array: a select chain over scalar registers)
-            d1 = (q == word) ? dg.w[0][q] : d1;
-            d2 = (q == word) ? dg.w[1][q] : d2;
-            d3 = (q == word) ? dg.w[2][q] : d3;
+        for (int q = 0; q < 6; q++) {  // (no runtime-indexed argument array: a select chain over scalar registers)
+#pragma unroll
+            for (int h = 0; h < 6; h++) d[h] = (q == word) ? dg.w[h][q] : d[h];
         }
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             int win = word * 4 + k;
-            auto step = [&](uint32_t packed, uint32_t t) {
-                int d = (int)(int8_t)((packed >> (8 * k)) & 0xffu);
-                if (d == 0) return;  // wave-uniform
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            if (win >= FT_WINDOWS) break;
+            auto step = [&](uint32_t packed, uint32_t t, bool lambda_half) {
+                int dv = (int)(int8_t)((packed >> (8 * k)) & 0xffu);
+                if (dv == 0) return;  // wave-uniform
+                uint32_t mag = (uint32_t)(dv < 0 ? -dv : dv);
                 AffN e = ft_load(tab + ((size_t)(win * FT_MULT + (int)mag - 1) * cnt + (j + t * m - lo)) * FT_WORDS);
-                acc = jac_madd(acc, aff_cneg(e, d < 0));
+                if (lambda_half && !aff_is_inf(e)) e.x = fq_mul(e.x, beta);  // lambda (x, y) = (beta x, y)
+                acc = jac_madd(acc, aff_cneg(e, dv < 0));
             };
-            step(d1, 1);
-            step(d2, 2);
-            step(d3, 3);
+            step(d[0], 1, false); step(d[1], 1, true);
+            step(d[2], 2, false); step(d[3], 2, true);
+            step(d[4], 3, false); step(d[5], 3, true);
         }
     }
     return acc;
@@ -152,14 +153,22 @@ __global__ __launch_bounds__(256, 2) void k_fold_tab4(const uint32_t *__restrict
 }
 
 // ---- host side
-// signed base-16 digits of a scalar: 64 digits in [-8, 8] (the value is below 2^255: the top nibble is at most 7, + carry 8)
-static void signed_digits16(const host::Fr &s_mont, int8_t out[64]) {
-    host::Fr c = s_mont.from_mont();
+// signed base-64 digits of a GLV half (256-bit two's complement, |k| < 2^129): 22 digits in [-32, 32], sign of k folded in
+static void signed_digits64(const uint64_t k[4], int8_t out[FT_WINDOWS]) {
+    uint64_t mag[4] = {k[0], k[1], k[2], k[3]};
+    bool neg = (k[3] >> 63) != 0;
+    if (neg) {  // two's complement negation
+        uint64_t carry = 1;
+        for (int i = 0; i < 4; ++i) { mag[i] = ~mag[i] + carry; carry = (carry && mag[i] == 0) ? 1 : 0; }
+    }
     int carry = 0;
-    for (int i = 0; i < 64; ++i) {
-        int v = (int)((c.l[i / 16] >> (4 * (i % 16))) & 15u) + carry;
-        if (v > 8) { v -= 16; carry = 1; } else carry = 0;
-        out[i] = (int8_t)v;
+    for (int i = 0; i < FT_WINDOWS; ++i) {
+        int bit = FT_BITS * i, w = bit >> 6, sh = bit & 63;
+        uint64_t v = mag[w] >> sh;
+        if (sh > 64 - FT_BITS && w + 1 < 4) v |= mag[w + 1] << (64 - sh);
+        int dgt = (int)(v & ((1u << FT_BITS) - 1u)) + carry;
+        if (dgt > FT_MULT) { dgt -= 1 << FT_BITS; carry = 1; } else carry = 0;
+        out[i] = (int8_t)(neg ? -dgt : dgt);
     }
 }
 
@@ -177,7 +186,7 @@ static int foldtab_build(halo_ctx *ctx) {
     const size_t bytes = (size_t)FT_ENTRIES * cnt * FT_WORDS * 4;
     auto t0 = std::chrono::steady_clock::now();
     uint32_t *tab = nullptr, *tmp = nullptr;
-    size_t slice = cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15);  // 32768 points x 512 entries x 200 B = 3.4 GB of temporaries
+    size_t slice = cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15);  // 32768 points x 704 entries x 200 B = 4.6 GB of temporaries
     hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tab, bytes);
     if (e == hipSuccess) e = hipMalloc(&tmp, (size_t)FT_ENTRIES * slice * FT_TMP_WORDS * 4);
     for (size_t off = 0; off < cnt && e == hipSuccess; off += slice) {
@@ -219,11 +228,15 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
     }
     FoldDigits dg;
     for (int t = 0; t < 3; ++t) {
-        int8_t d[64];
-        signed_digits16(s[t], d);
-        for (int q = 0; q < 16; ++q)
-            dg.w[t][q] = (uint32_t)(uint8_t)d[4 * q] | ((uint32_t)(uint8_t)d[4 * q + 1] << 8) | ((uint32_t)(uint8_t)d[4 * q + 2] << 16) |
-                         ((uint32_t)(uint8_t)d[4 * q + 3] << 24);
+        uint64_t k[2][4];
+        host::glv_decompose(s[t], k[0], k[1]);  // s = k1 + k2 lambda
+        for (int h = 0; h < 2; ++h) {
+            int8_t d[24] = {0};
+            signed_digits64(k[h], d);
+            for (int q = 0; q < 6; ++q)
+                dg.w[2 * t + h][q] = (uint32_t)(uint8_t)d[4 * q] | ((uint32_t)(uint8_t)d[4 * q + 1] << 8) | ((uint32_t)(uint8_t)d[4 * q + 2] << 16) |
+                                     ((uint32_t)(uint8_t)d[4 * q + 3] << 24);
+        }
     }
     size_t half = m >= 512 ? (m + 1) / 2 : m;
     size_t lo = ctx->n / 4, cnt = ctx->n - lo;

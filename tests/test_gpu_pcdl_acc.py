@@ -491,7 +491,7 @@ def test_open_with_fold_table_matches_oracle(hal, lg):
             assert c.info(1) == 0
             c.set_fold_table(1)
             got = pcdl.open(c, [77], coeffs, C, d, zw[0], w)
-            assert c.info(1) == 512 * 64 * (n - n // 4), "the table covers the upper three quarters of the key"
+            assert c.info(1) == 704 * 64 * (n - n // 4), "the table covers the upper three quarters of the key"
             assert got.tolist() == want.tolist()
             assert pcdl.open(c, [77], coeffs, C, d, zw[0], w).tolist() == want.tolist()  # (table already there)
             if ppl is not None:
@@ -554,7 +554,7 @@ def test_open_2_19_fold_table_matches_oracle_fixture(hal):
             C = pcdl.commit(c, coeffs, d, w)
             pi = pcdl.open(c, [fx["open_seed"]], coeffs, C, d, zw[0], w)
             assert hashlib.sha256(pi.tobytes()).hexdigest() == case["proof_sha256"]
-        assert c.info(1) == 512 * 64 * (n - n // 4) and c.info(2) > 0
+        assert c.info(1) == 704 * 64 * (n - n // 4) and c.info(2) > 0
     finally:
         c.close()
 
