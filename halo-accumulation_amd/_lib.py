@@ -130,6 +130,7 @@ _SIGS = {
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "halo_set_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_test_glv_digits": (C.c_int, [u64p, C.POINTER(C.c_uint8), C.POINTER(C.c_int)]),
+    "halo_test_fold_digits": (C.c_int, [u64p, C.POINTER(C.c_int8)]),
     "halo_test_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u64p, u64p, C.c_size_t, u64p]),
     "halo_test_point_op": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_size_t, u64p]),
 }

@@ -996,6 +996,11 @@ int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n_out) {
     *n_out = dg.n;
     return HALO_OK;
 }
+int halo_test_fold_digits(const uint64_t s[4], int8_t out[44]) {
+    if (!s || !out) { set_error("fold_digits: null pointer"); return HALO_E_ARG; }
+    fold_digits_host(host::Fr::load(s), out);
+    return HALO_OK;
+}
 int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out) {
     HALO_CTX(ctx);
     if (!rng_state || (n && !d_out)) { set_error("rng_scalars: null pointer"); return HALO_E_ARG; }

@@ -172,6 +172,14 @@ static void signed_digits64(const uint64_t k[4], int8_t out[FT_WINDOWS]) {
     }
 }
 
+// test hook (host only): the 2 x 22 digits the fold kernel walks for scalar s
+void fold_digits_host(const host::Fr &s, int8_t out[2 * FT_WINDOWS]) {
+    uint64_t k1[4], k2[4];
+    host::glv_decompose(s, k1, k2);
+    signed_digits64(k1, out);
+    signed_digits64(k2, out + FT_WINDOWS);
+}
+
 void foldtab_release(halo_ctx *ctx) {
     if (!ctx->d_foldtab) return;
     alloc_epoch_bump(ctx);

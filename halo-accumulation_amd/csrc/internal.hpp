@@ -318,6 +318,7 @@ int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_
 // ---- foldtab.hip: the first two-level fold of an open from a comb table over the context's key
 int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]);  // 1 = done, 0 = not applicable
 void foldtab_release(halo_ctx *ctx);
+void fold_digits_host(const host::Fr &s, int8_t out[44]);
 
 // ---- multi.hip: MSMs over the key of a multi-device context, cut along the shards' blocks
 int multi_attach_shards(halo_ctx *ctx, const int *devices, int n_dev, const uint64_t *bases_affine, uint64_t first_index);

@@ -300,6 +300,9 @@ int halo_set_task_len(halo_ctx *ctx, int len);
 /* host-only: base-2 expansion of the fold scalar over the Eisenstein units (host_math.hpp glv_digits):
  * out[i] = digit code of 2^i (0 none, 1..3 = +lambda^0..2, 4..6 = -lambda^0..2), *n = number of digits */
 int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n);
+/* host-only: the comb digits of the table fold (foldtab.hip): s = k1 + k2 lambda, out[0..22) = signed base-64 digits of k1
+ * (each in [-32, 32]), out[22..44) = those of k2 */
+int halo_test_fold_digits(const uint64_t s[4], int8_t out[44]);
 int halo_test_field_op(halo_ctx *ctx, int field /*0 Fq, 1 Fr*/, int op /*0 mul,1 add,2 sub,3 inv,4 from_mont,5 to_mont*/,
                        const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 /* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs);

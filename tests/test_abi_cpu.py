@@ -117,3 +117,22 @@ def test_glv_digits_host(hal):
             nonzero += sum(1 for i in range(n.value) if out[i]); total += n.value
     assert 0.5 < nonzero / total < 0.66
 
+
+
+def test_fold_comb_digits_host(hal):
+    """the digits the comb-table fold walks (foldtab.hip): s == k1 + k2 lambda (mod r) with k_h = sum_i d_i 64^i, 22 digits
+    per half, each in [-32, 32] (the table holds the multiples 1..32)"""
+    import pallas_model as pm
+    lib = hal.load()
+    lam = 0x6819a58283e528e511db4d81cf70f5a0fed467d47c033af2aa9d2e050aa0e4f
+    rng = pm.SplitMix64(11)
+    xs = [0, 1, 2, 31, 32, 33, 63, 64, pm.R_ORDER - 1, pm.R_ORDER - 32, lam, lam + 1, pm.R_ORDER - lam, (1 << 254) % pm.R_ORDER, lam * lam % pm.R_ORDER]
+    xs += [rng.next_scalar() for _ in range(500)]
+    for x in xs:
+        out = (C.c_int8 * 44)()
+        assert lib.halo_test_fold_digits(hal._lib.ptr(orc.fr_to_mont(x)), out) == 0
+        assert all(-32 <= out[i] <= 32 for i in range(44))
+        k1 = sum(int(out[i]) << (6 * i) for i in range(22))
+        k2 = sum(int(out[22 + i]) << (6 * i) for i in range(22))
+        assert abs(k1) < 1 << 129 and abs(k2) < 1 << 129
+        assert (k1 + k2 * lam - x) % pm.R_ORDER == 0
