@@ -27,6 +27,7 @@ cp(os.path.join(ev, "open_timeline.txt"), "open_check_timeline.txt")
 cp(os.path.join(ev, "pmc_traffic.json"), "pmc_traffic.json")
 cp(os.path.join(ev, "pmc_fr.json"), "pmc_open.json")
 cp(os.path.join(ev, "fr_kernels_events.json"), "fr_kernels_events.json")
+cp(os.path.join(ev, "pmc_open_kernels.json"), "pmc_open_loop.json")
 cp(os.path.join(ev, "fr29_bench.txt"), "microbench_fr29_product.txt")
 cp(os.path.join(ev, "asdl64.json"), "asdl64_n2_20.json")
 for n in (2, 4, 8):

@@ -24,6 +24,10 @@ step fr_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --out
 python tools/pmc_summary.py $OUT/fr_fetch $OUT/fr_write "python3 tools/fr_kernels.py 20 6" > $OUT/pmc_fr.json || exit 1
 python tools/fr_kernels.py 20 20 > $OUT/fr_kernels_events.json 2>/dev/null || exit 1
 ( cd tools && ./fr29_bench > ../$OUT/fr29_bench.txt 2>&1 ) || true
+# HBM-side bytes of the kernels of an open (the comb-table fold among them)
+step open_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/open_fetch -- python3 tools/open_loop.py 20 4 > $OUT/open_fetch.log 2>&1 || exit 1
+step open_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/open_write -- python3 tools/open_loop.py 20 4 > $OUT/open_write.log 2>&1 || exit 1
+python tools/pmc_summary.py $OUT/open_fetch $OUT/open_write "python3 tools/open_loop.py 20 4" > $OUT/pmc_open_kernels.json || exit 1
 # multi-device context from ONE process (halo_ctx_create_urs_multi), the one GPU of this box standing in for every device
 for N in 2 4 8; do
   step oneproc$N; timeout -k 10 300 python bench.py --gpus $N --one-process --devices $(python -c "print(','.join(['0']*$N))") --steps 64 --min-seconds 0.3 > $OUT/bench_oneproc$N.json 2> $OUT/bench_oneproc$N.err || exit 1
