@@ -1545,6 +1545,8 @@ static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) {
     static const int small_env = getenv("HALO_SMSM_KMAX") ? atoi(getenv("HALO_SMSM_KMAX")) : 0;  // development override
     if (ctx->task_len > 0) return (uint32_t)ctx->task_len;
     if (small_env > 0 && n <= ((size_t)1 << 16)) return (uint32_t)small_env;
+    static const int late_env = getenv("HALO_LATE_KMAX") ? atoi(getenv("HALO_LATE_KMAX")) : 0;  // development override
+    if (n <= ((size_t)1 << 14)) return late_env > 0 ? (uint32_t)late_env : 8u;  // the IPA's late rounds: the chain is the round's latency (measured: 16 -> 8: -0.15 ms per open)
     return n >= ((size_t)1 << 18) ? KMAX : 16u;
 }
 
