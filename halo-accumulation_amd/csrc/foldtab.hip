@@ -228,7 +228,9 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
     if (!ctx->d_foldtab) {
         // mode 1: at the first full-size open; default: at the second (a context that opens once never pays the build)
         ctx->foldtab_opens++;
-        bool now = ctx->fold_table_mode == 1 || (ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->foldtab_opens >= 2);
+        // (automatic mode also stops at 2^21 points: 71 GB; larger keys on request only)
+        bool now = ctx->fold_table_mode == 1 ||
+                   (ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21) && ctx->foldtab_opens >= 2);
         if (!now) return 0;
         int rc = foldtab_build(ctx);
         if (rc) return rc;
