@@ -667,6 +667,13 @@ void ipa_set_hprime_scalar(halo_ipa *st, const host::Fr &xi0) {
 extern "C" {
 
 
+// HALO_IPA_TIMING=1: where the host side of a round goes (printed when the state is destroyed; development aid)
+namespace {
+struct RoundTiming { double enqueue = 0, dots = 0, hterm = 0, wait = 0, combine = 0, fold = 0; long rounds = 0; };
+thread_local RoundTiming g_rt;
+const bool g_rt_on = getenv("HALO_IPA_TIMING") != nullptr;
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
 // <c_r, G_l>, <c_l, G_r> and the two dot products of one round, without the H' terms
 static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_out, host::Point *Rp_out, bool with_hterm) {
     halo_ctx *ctx = st->ctx;
@@ -675,6 +682,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     int rc;
     bool batched = false;
     host::Point Lp, Rp;
+    double t0 = g_rt_on ? now_us() : 0;
     // <c_r, G_l> on slot 0 and <c_l, G_r> on slot 1 run concurrently; the other streams first wait
     // for everything queued on stream 0 (the previous round's folds)
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
@@ -707,6 +715,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         rc = msm_enqueue(ctx, 1, st->d_G + 32 * m, st->d_c, true, m);
     }
     if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
+    double t1 = g_rt_on ? now_us() : 0;
     // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream while the MSMs run
     hipStream_t saved = ctx->stream;
     ctx->stream = ctx->streams[2];
@@ -715,6 +724,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     // Window combine (~250 doublings), the H' term and the normalisation of L start on the helper thread as soon as L's
     // launches are done, while this thread still waits for R's and then does R's: pure host arithmetic on both sides.
     // the H' terms only need the dot products: computed now, while the MSMs are still running
+    double t2 = g_rt_on ? now_us() : 0;
     host::Point hterm[2] = {host::Point::infinity(), host::Point::infinity()};
     if (with_hterm && !rcd)
         for (int k = 0; k < 2; ++k) hterm[k] = st->hp_from_scalar ? public_h_table().mul(dots[k] * st->hp_scalar) : st->hp_table.mul(dots[k]);
@@ -725,19 +735,32 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         if (with_hterm) p = (p + hterm[which]).normalized();
         *out = p;
     };
+    double t3 = g_rt_on ? now_us() : 0;
     rc = msm_wait(ctx, 0, batched ? 2 : 1);
+    double t4 = g_rt_on ? now_us() : 0;
     bool l_started = !rc && !rcd;
     if (l_started) ctx->worker.submit([&finish_one, &Lp] { finish_one(0, &Lp); });
     int rc2 = batched ? HALO_OK : msm_wait(ctx, 1, 1);
     if (!rc && !rc2 && !rcd) finish_one(1, &Rp);
     if (l_started) ctx->worker.wait();
+    if (g_rt_on) {
+        double t5 = now_us();
+        g_rt.enqueue += t1 - t0; g_rt.dots += t2 - t1; g_rt.hterm += t3 - t2; g_rt.wait += t4 - t3; g_rt.combine += t5 - t4; g_rt.rounds++;
+    }
     if (rc || rc2 || rcd) return rc ? rc : (rc2 ? rc2 : rcd);
     *Lp_out = Lp;
     *Rp_out = Rp;
     return HALO_OK;
 }
 
+static int ipa_round_fold_impl(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_inv[4]);
 int halo_ipa_round_fold(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_inv[4]) {
+    double t0 = g_rt_on ? now_us() : 0;
+    int rc = ipa_round_fold_impl(st, xi, xi_inv);
+    if (g_rt_on) g_rt.fold += now_us() - t0;
+    return rc;
+}
+static int ipa_round_fold_impl(halo_ipa *st, const uint64_t xi[4], const uint64_t xi_inv[4]) {
     if (!st) { set_error("null ipa state"); return HALO_E_ARG; }
     halo_ctx *ctx = st->ctx;
     HALO_CTX(ctx);
@@ -843,6 +866,11 @@ int halo_ipa_finish_z(halo_ipa *st, uint64_t U[12], uint64_t c[4], uint64_t z0[4
 
 void halo_ipa_destroy(halo_ipa *st) {
     if (!st) return;
+    if (g_rt_on && g_rt.rounds) {
+        fprintf(stderr, "[halo] ipa host time over %ld rounds (us): enqueue %.0f  dot launch + wait %.0f  H' terms %.0f  wait for the MSMs %.0f  combine %.0f  fold calls %.0f\n",
+                g_rt.rounds, g_rt.enqueue, g_rt.dots, g_rt.hterm, g_rt.wait, g_rt.combine, g_rt.fold);
+        g_rt = RoundTiming();
+    }
     halo_ctx *ctx = st->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
