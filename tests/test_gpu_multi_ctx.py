@@ -147,3 +147,18 @@ def test_multi_ctx_argument_errors(hal):
         hal.Context(urs_n=4096, devices=[0, 99])
     with pytest.raises(hal.HaloError):
         hal.Context(urs_n=4096, devices=[])
+
+
+@pytest.mark.parametrize("n,P", [(10, 8), (64, 8), (1000, 3), (4097, 5)])
+def test_multi_ctx_small_and_ragged_keys(hal, n, P):
+    """keys smaller than 4 points per shard (some shards are empty), sizes that are no multiple of the shard count"""
+    gs = orc.urs_affine(2, n)
+    c = hal.Context(gs, devices=[0] * P)
+    try:
+        sc, _ = orc.rng_scalars(0xBEE5 + n, n)
+        assert c.msm(sc).tolist() == orc.msm_affine(gs, sc).tolist()
+        if n > 20:
+            assert c.msm(sc[:n - 13], off=5).tolist() == orc.msm_affine(gs[5:n - 8], sc[:n - 13]).tolist()
+        assert c.msm(sc[:0]).tolist() == orc.msm_affine(gs[:0], sc[:0]).tolist()   # the empty MSM: infinity
+    finally:
+        c.close()

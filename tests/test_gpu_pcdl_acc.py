@@ -515,6 +515,42 @@ def test_open_with_fold_table_matches_oracle(hal, lg):
         c.close()
 
 
+def test_msm_affine_more_generators_than_the_context_holds(hal, ctx):
+    """halo_msm_affine over more generators than the context has points: consecutive chunks, partial sums added on the host"""
+    from halo_accumulation_amd import group
+    m = 3 * 4096 + 77
+    Gs = orc.urs_affine(50000, m)
+    ms, _ = orc.rng_scalars(0xC0FFEE, m)
+    assert group.point_dot_affine(ctx, ms, Gs=Gs).tolist() == orc.msm_affine(Gs, ms).tolist()
+
+
+def test_open_with_fold_table_and_an_infinity_in_the_key(hal):
+    """a key that holds the point at infinity (halo_ctx_create takes any bases): its table entries are infinity, the folds
+    skip them, proofs equal the generic kernel's and the oracle's"""
+    from halo_accumulation_amd import pcdl
+    n, d = 256, 255
+    gs = orc.urs_affine(2, n).copy()
+    gs[200] = 0
+    gs[77] = 0
+    c = hal._lib.Context(gs)
+    try:
+        c.set_ipa_switch(4)
+        ppl = orc.make_pp(gs)
+        coeffs, s = orc.rng_scalars(0x1F, n - 1)
+        zw, _ = orc.rng_scalars(s, 2)
+        for w in (None, zw[1]):
+            C = pcdl.commit(c, coeffs, d, w)
+            assert C.tolist() == orc.pcdl_commit(ppl, coeffs, d, w).tolist()
+            c.set_fold_table(0)
+            want = pcdl.open(c, [3], coeffs, C, d, zw[0], w)
+            c.set_fold_table(1)
+            got = pcdl.open(c, [3], coeffs, C, d, zw[0], w)
+            ref, _ = orc.pcdl_open(ppl, 3, coeffs, C, d, zw[0], w)
+            assert got.tolist() == want.tolist() == ref.tolist()
+    finally:
+        c.close()
+
+
 def test_fold_table_memory_failure_falls_back(hal, monkeypatch):
     """no memory for the comb table: one line on stderr, the generic fold kernel runs, same proof, no second attempt"""
     from halo_accumulation_amd import pcdl
