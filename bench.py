@@ -102,8 +102,10 @@ def main():
         batch = 8 if per_rank < (1 << 18) else 4 if per_rank < (1 << 19) else 2 if per_rank < (1 << 20) else 1
     else:
         batch = 1 if world <= 2 else 4
-    if one_proc:
-        batch = 1
+    if one_proc and args.batch <= 0:
+        # every shard of the multi-device context runs its index block of a batch as one launch (multi.hip multi_batch_begin)
+        shard_pts = n // len(devices)
+        batch = 8 if shard_pts < (1 << 18) else 4 if shard_pts < (1 << 19) else 2 if shard_pts < (1 << 20) else 1
     window_mode = world > 1 and args.shard == "window"
     if window_mode:
         # every rank holds the whole key and all scalars (128 + 32 MiB at n = 2^20 of 288 GiB) and computes
@@ -161,7 +163,7 @@ def main():
 
         def finish():
             slot, m = pending.pop(0)
-            partials = [ctx.msm_dev_end(slot)] if one_proc else ctx.msm_dev_batch_end(slot, m)
+            partials = ctx.msm_dev_batch_end(slot, m)
             gathers.append(gather.gather_start([partials[j] for j in range(m)]))  # one all-gather per launch, asynchronous
             while len(gathers) > 1:
                 collect()
@@ -172,10 +174,7 @@ def main():
             if len(pending) == depth:
                 finish()
             slot = launches % depth
-            if one_proc:
-                ctx.msm_dev_begin(slot, ptrs[0], n)  # fans out over the shards (multi.hip)
-            else:
-                ctx.msm_dev_batch_begin(slot, ptrs[:m], hi - lo, part=part, parts=parts)
+            ctx.msm_dev_batch_begin(slot, ptrs[:m], hi - lo, part=part, parts=parts)  # (a multi-device context fans the batch out over its shards)
             pending.append((slot, m))
             launches += 1
             k -= m
@@ -254,7 +253,7 @@ def main():
         ovl_cnt = n_launches if ovl_cnt else 0
         # 64 B base + 32 B scalar per point, one point out; a launch carries `batch` MSMs (their
         # index block or their 1/parts window share on this rank)
-        alg_bytes = batch * (96 * (hi - lo) // parts + 64) if not one_proc else 96 * (n // len(devices)) + 64
+        alg_bytes = batch * (96 * (hi - lo) // parts + 64) if not one_proc else batch * (96 * (n // len(devices)) + 64)
         # HBM-side bytes per launch: PMC counters need a rocprofv3 --pmc pass of their own (tools/evidence.sh), they cannot be
         # read inside this run -- the figure is STATIC, taken from the committed pass named in traffic_source
         traffic, traffic_source = None, None

@@ -306,6 +306,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     (void)hipFree(ctx->d_poly2);
     (void)hipFree(ctx->d_verify);
     for (auto p : ctx->d_slot_scalars) (void)hipFree(p);
+    for (auto p : ctx->d_batch_scalars) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_wintab) (void)hipHostFree(ctx->h_wintab);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
@@ -362,7 +363,9 @@ int halo_msm_dev_end(halo_ctx *ctx, int slot, uint64_t out[12]) {
     HALO_CTX(ctx);
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
     host::Point r;
-    int rc = (!ctx->shards.empty() && slot >= 0 && slot < HALO_SLOTS && ctx->fan[slot].active) ? multi_end(ctx, slot, &r) : msm_finish(ctx, slot, &r);
+    bool fanned = !ctx->shards.empty() && slot >= 0 && slot < HALO_SLOTS && ctx->fan[slot].active;
+    if (fanned && ctx->fan[slot].batch > 0) { set_error("msm: this slot holds a batch (halo_msm_dev_batch_end collects it)"); return HALO_E_ARG; }
+    int rc = fanned ? multi_end(ctx, slot, &r) : msm_finish(ctx, slot, &r);
     if (rc) return rc;
     r.store_normalized(out);
     return HALO_OK;
@@ -381,13 +384,15 @@ int halo_msm_dev_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, cons
         if (n && !d_scalars[b]) { set_error("msm: null scalar pointer in batch"); return HALO_E_ARG; }
         members.scalars[b] = static_cast<const uint64_t *>(d_scalars[b]);
     }
+    if (!ctx->shards.empty() && parts == 1) return multi_batch_begin(ctx, slot, off, n, members, mont != 0);
     return msm_enqueue_batch(ctx, slot, ctx->d_bases + 32 * off, members, mont != 0, n);
 }
 int halo_msm_dev_batch_end(halo_ctx *ctx, int slot, size_t batch, uint64_t *out) {
     HALO_CTX(ctx);
     if (!out || batch < 1 || batch > (size_t)MSM_MAX_BATCH) { set_error("msm: null output or bad batch"); return HALO_E_ARG; }
     host::Point r[MSM_MAX_BATCH];
-    int rc = msm_finish_batch(ctx, slot, r, (int)batch);
+    bool fanned = !ctx->shards.empty() && slot >= 0 && slot < HALO_SLOTS && ctx->fan[slot].active && ctx->fan[slot].batch > 0;
+    int rc = fanned ? multi_batch_end(ctx, slot, r, (int)batch) : msm_finish_batch(ctx, slot, r, (int)batch);
     if (rc) return rc;
     for (size_t b = 0; b < batch; ++b) r[b].store_normalized(out + 12 * b);
     return HALO_OK;

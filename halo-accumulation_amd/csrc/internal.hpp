@@ -246,6 +246,8 @@ struct halo_ctx {
     size_t tmp_words = 0;
     uint64_t *h_pinned = nullptr;  // small pinned staging (4 KiB)
     uint64_t *h_wintab = nullptr;  // pinned staging of a window table of powers (ipa.hip upload_window_table), 8 KiB
+    uint64_t *d_batch_scalars[HALO_SLOTS] = {};  // a shard's peer copies of a batch's scalar arrays (multi.hip), grown on demand
+    size_t batch_scalars_bytes[HALO_SLOTS] = {};
     uint64_t *d_slot_scalars[HALO_SLOTS] = {};  // host-scalar MSMs (halo_msm, halo_msm_begin): one staging buffer of n x 4 words per slot, first use
     uint64_t *d_verify = nullptr;  // staging of the batched verifier (points, scalars, challenges, results), grown on demand
     size_t verify_words = 0;
@@ -258,7 +260,7 @@ struct halo_ctx {
     std::vector<halo_ctx *> shards;
     std::vector<size_t> shard_lo;  // shards.size() + 1 block boundaries
     halo_ctx *parent = nullptr;    // set on a shard
-    struct Fan { bool active = false; std::vector<char> used; };
+    struct Fan { bool active = false; int batch = 0; std::vector<char> used; };  // batch: members of a batched launch (0: a single MSM)
     Fan fan[HALO_SLOTS];           // which shards hold a stretch of the MSM in flight on each slot
 };
 
@@ -326,6 +328,8 @@ void multi_destroy(halo_ctx *ctx);
 bool multi_takes(const halo_ctx *ctx, const uint32_t *d_bases, size_t n);  // a stretch of the parent's own key?
 int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *host_scalars, const uint64_t *dev_scalars, bool mont);
 int multi_end(halo_ctx *ctx, int slot, host::Point *out);
+int multi_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const MsmBatch &members, bool mont);
+int multi_batch_end(halo_ctx *ctx, int slot, host::Point *out, int count);
 int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, bool mont, host::Point *out);
 int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
 

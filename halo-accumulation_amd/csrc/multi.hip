@@ -119,6 +119,7 @@ int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *h
             }
     (void)hipSetDevice(ctx->device);
     fan.active = true;  // (also after a failure: multi_end drains whatever was enqueued)
+    fan.batch = 0;
     if (rc) { host::Point dummy; std::string keep = halo_last_error(); (void)multi_end(ctx, slot, &dummy); set_error(keep); }
     return rc;
 }
@@ -152,6 +153,86 @@ int multi_end(halo_ctx *ctx, int slot, host::Point *out) {
     fan.active = false;
     (void)hipSetDevice(ctx->device);
     *out = acc;
+    return rc;
+}
+
+// Batched form (halo_msm_dev_batch_begin/_end): `members.count` MSMs over GS[off, off + n), one resident scalar array each.
+// Every shard runs ITS stretch of all members as one batched launch sequence (which is what makes a 2^17-point block a full
+// launch: msm.hip, small-key table plan), and the shards' per-member partials are added in block order.
+int multi_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const MsmBatch &members, bool mont) {
+    if (slot < 0 || slot >= HALO_SLOTS) { set_error("msm: slot out of range"); return HALO_E_ARG; }
+    halo_ctx::Fan &fan = ctx->fan[slot];
+    if (fan.active) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    if (members.parts != 1) { set_error("msm: window shards are not split over the devices of a multi-device context"); return HALO_E_ARG; }
+    const int P = (int)ctx->shards.size();
+    fan.used.assign((size_t)P, 0);
+    int rc = HALO_OK;
+    for (int k = 0; k < P && !rc; ++k) {
+        size_t lo = ctx->shard_lo[k], hi = ctx->shard_lo[k + 1];
+        size_t a = std::max(off, lo), b = std::min(off + n, hi);
+        if (a >= b) continue;
+        halo_ctx *s = ctx->shards[k];
+        fan.used[k] = 1;
+        hipError_t e = hipSetDevice(s->device);
+        MsmBatch mine = members;
+        for (int m = 0; m < members.count && e == hipSuccess; ++m) {
+            const uint64_t *src = members.scalars[m] + 4 * (a - off);
+            int src_dev = device_of(src, ctx->device);
+            if (src_dev != s->device || getenv("HALO_TEST_FORCE_PEER_COPY")) {  // (as multi_begin: peer copy in front of the launches)
+                size_t need = (size_t)members.count * (s->n < 64 ? 64 : s->n) * 32;
+                if (s->batch_scalars_bytes[slot] < need) {
+                    alloc_epoch_bump(s);
+                    (void)hipStreamSynchronize(s->streams[slot]);
+                    (void)hipFree(s->d_batch_scalars[slot]);
+                    s->d_batch_scalars[slot] = nullptr;
+                    s->batch_scalars_bytes[slot] = 0;
+                    e = hipMalloc(&s->d_batch_scalars[slot], need);
+                    if (e == hipSuccess) s->batch_scalars_bytes[slot] = need;
+                }
+                uint64_t *dst = s->d_batch_scalars[slot] + (size_t)m * (s->n < 64 ? 64 : s->n) * 4;
+                if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, s->device, src, src_dev, (b - a) * 32, s->streams[slot]);
+                src = dst;
+            }
+            mine.scalars[m] = src;
+            mine.base_off[m] = 0;
+        }
+        rc = e != hipSuccess ? hip_fail(e, "multi-device MSM: peer copy of the scalars") : msm_enqueue_batch(s, slot, s->d_bases + 32 * (a - lo), mine, mont, b - a);
+    }
+    (void)hipSetDevice(ctx->device);
+    fan.active = true;
+    fan.batch = members.count;
+    if (rc) { host::Point dummy[MSM_MAX_BATCH]; std::string keep = halo_last_error(); (void)multi_batch_end(ctx, slot, dummy, members.count); set_error(keep); }
+    return rc;
+}
+int multi_batch_end(halo_ctx *ctx, int slot, host::Point *out, int count) {
+    if (slot < 0 || slot >= HALO_SLOTS || !ctx->fan[slot].active) { set_error("msm: nothing in flight on this slot"); return HALO_E_ARG; }
+    halo_ctx::Fan &fan = ctx->fan[slot];
+    if (fan.batch != count) { set_error("msm: this slot holds a batch of a different size"); return HALO_E_ARG; }
+    const int P = (int)ctx->shards.size();
+    std::vector<host::Point> part((size_t)P * MSM_MAX_BATCH, host::Point::infinity());
+    std::vector<int> rcs((size_t)P, HALO_OK);
+    std::vector<std::string> errs((size_t)P);
+    for (int k = 0; k < P; ++k) {
+        if (!fan.used[k]) continue;
+        halo_ctx *s = ctx->shards[k];
+        if (!s->wss[slot].in_flight) { fan.used[k] = 0; continue; }
+        s->worker.submit([s, slot, k, count, &part, &rcs, &errs] {
+            (void)hipSetDevice(s->device);
+            rcs[k] = msm_finish_batch(s, slot, &part[(size_t)k * MSM_MAX_BATCH], count);
+            if (rcs[k]) errs[k] = halo_last_error();
+        });
+    }
+    int rc = HALO_OK;
+    for (int m = 0; m < count; ++m) out[m] = host::Point::infinity();
+    for (int k = 0; k < P; ++k) {
+        if (!fan.used[k]) continue;
+        ctx->shards[k]->worker.wait();
+        if (rcs[k] && !rc) { rc = rcs[k]; set_error(errs[k]); }
+        for (int m = 0; m < count; ++m) out[m] = out[m] + part[(size_t)k * MSM_MAX_BATCH + m];  // block order 0 .. P-1
+    }
+    fan.active = false;
+    fan.batch = 0;
+    (void)hipSetDevice(ctx->device);
     return rc;
 }
 

@@ -60,7 +60,8 @@ int halo_ctx_create_urs_strided(int device, uint64_t first_index, uint64_t strid
  * 2^16 points are cut along the block boundaries: each shard runs its stretch on its own device and stream, the partial
  * points are added on the host in block order -- the same normalised point as on one device.  Device-resident scalars
  * are read in place on their own GPU and copied peer-to-peer (xGMI) to the others; host scalars go to each device over its
- * own PCIe link.  The window-shard and batch forms (halo_msm_dev_begin_part, halo_msm_dev_batch_*) stay on devices[0]. */
+ * own PCIe link.  halo_msm_dev_batch_begin/_end fan out the same way (every shard runs its stretch of all members as one batched
+ * launch); the window-shard form (part / parts != 0 / 1) stays on devices[0]. */
 int halo_ctx_create_multi(const int *devices, int n_dev, const uint64_t *bases_affine, size_t n, halo_ctx **out);
 int halo_ctx_create_urs_multi(const int *devices, int n_dev, uint64_t first_index, size_t n, halo_ctx **out);
 int halo_ctx_devices(const halo_ctx *ctx); /* shards of a multi-device context, 1 for a plain one */

@@ -77,6 +77,39 @@ def test_multi_ctx_2_20_equals_single_context(hal, P):
         c.close()
 
 
+@pytest.mark.parametrize("P,batch", [(2, 2), (4, 4), (8, 8), (3, 5)])
+def test_multi_ctx_batched_launches(hal, P, batch, monkeypatch):
+    """halo_msm_dev_batch_begin/_end on a multi-device context: every shard runs its stretch of all members as one batched
+    launch; member b equals the plain context's MSM over scalar set b (also with the peer-copy path forced)"""
+    import torch
+    n = 1 << 19
+    ds = [torch.empty(n * 4, dtype=torch.int64, device="cuda") for _ in range(batch)]
+    one = hal.Context(urs_n=n)
+    try:
+        for b, d in enumerate(ds):
+            one.rng_scalars_dev(0x5E7 + 97 * b, n, d.data_ptr())
+        torch.cuda.synchronize()
+        want = [one.msm_dev(d.data_ptr(), n).tolist() for d in ds]
+        want_off = one.msm_dev(ds[-1].data_ptr() + 32 * 4096, n - 8192, off=4096).tolist()
+    finally:
+        one.close()
+    c = hal.Context(urs_n=n, devices=[0] * P)
+    try:
+        for forced in (False, True):
+            if forced:
+                monkeypatch.setenv("HALO_TEST_FORCE_PEER_COPY", "1")
+            for slot in (0, 1):
+                c.msm_dev_batch_begin(slot, [d.data_ptr() for d in ds], n)
+            for slot in (0, 1):
+                assert c.msm_dev_batch_end(slot, batch).tolist() == want
+            c.msm_dev_batch_begin(2, [ds[-1].data_ptr() + 32 * 4096], n - 8192, off=4096)
+            with pytest.raises(hal.HaloError):
+                c.msm_dev_end(2)                      # a batch is collected by the batch call
+            assert c.msm_dev_batch_end(2, 1)[0].tolist() == want_off
+    finally:
+        c.close()
+
+
 def test_multi_ctx_peer_copy_path(hal, monkeypatch):
     """Device-resident scalars on a GPU other than a shard's are copied peer-to-peer into the shard's slot buffer in front of
     its launches.  One GPU here, so the copy path is forced (HALO_TEST_FORCE_PEER_COPY): hipMemcpyPeerAsync between a
