@@ -98,17 +98,22 @@ def test_u_check(hal, ctx, ipa_mode):
     assert [orc.fr_from_mont(c) for c in ctx.h_coeffs(xm)] == [1, 3, 2, 6, 1, 3, 2, 6]
 
 
-@pytest.fixture(params=[(0, 1), (1 << 16, 2), (16, 1), (0, 2), (16, 2)],
-                ids=["always-fold", "default", "switch-at-16", "two-level-folds-to-the-end", "two-level-folds-switch-at-16"])
+@pytest.fixture(params=[(0, 1, 0), (1 << 16, 2, -1), (16, 1, 0), (0, 2, 0), (16, 2, 0), (0, 2, 1), (16, 2, 1)],
+                ids=["always-fold", "default", "switch-at-16", "two-level-folds-to-the-end", "two-level-folds-switch-at-16",
+                     "fold-table-two-level-folds-to-the-end", "fold-table-switch-at-16"])
 def ipa_mode(request, ctx):
     """Every IPA strategy must give the reference's results: folding G every round (k_fold_points), every other round
-    (two halvings per pass, k_fold_points4, L/R from MSMs over the unfolded key in between) and the no-fold late rounds
-    (MSMs over the fixed folded key)."""
+    (two halvings per pass, k_fold_points4, L/R from MSMs over the unfolded key in between), the first of those passes from
+    the comb table over the context's key (k_fold_tab4: only when the open has the size of the key) and the no-fold late
+    rounds (MSMs over the fixed folded key)."""
     ctx.set_ipa_switch(request.param[0])
     ctx.set_fold_levels(request.param[1])
+    ctx.set_fold_table(request.param[2])
     yield request.param
     ctx.set_ipa_switch(1 << 14)
     ctx.set_fold_levels(2)
+    ctx.set_fold_table(0)   # (release the table)
+    ctx.set_fold_table(-1)
 
 
 @pytest.mark.parametrize("n", [2, 8, 64, 1024])
