@@ -693,6 +693,16 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[2], st->ev, 0));
+    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream, issued BEFORE the MSMs' launches: queued
+    // behind them the two small kernels waited for the bucket kernel's waves to drain, and the H' terms, which need only
+    // the dot products, were computed after the MSMs instead of under them
+    {
+        hipStream_t saved = ctx->stream;
+        ctx->stream = ctx->streams[2];
+        int rcl = fr_dot2_launch(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m);
+        ctx->stream = saved;
+        if (rcl) return rcl;
+    }
     if (st->nofold) {
         rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
         if (rc) return rc;
@@ -721,11 +731,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     }
     if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
     double t1 = g_rt_on ? now_us() : 0;
-    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream while the MSMs run
-    hipStream_t saved = ctx->stream;
-    ctx->stream = ctx->streams[2];
-    int rcd = fr_dot2(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m, dots);
-    ctx->stream = saved;
+    int rcd = fr_dot2_collect(ctx, ctx->streams[2], m, dots);
     // Window combine (~250 doublings), the H' term and the normalisation of L start on the helper thread as soon as L's
     // launches are done, while this thread still waits for R's and then does R's: pure host arithmetic on both sides.
     // the H' terms only need the dot products: computed now, while the MSMs are still running

@@ -346,6 +346,8 @@ int ipa_fold_scalars(halo_ctx *ctx, uint64_t *d_c, uint64_t *d_z, size_t m, cons
 // out[0] = <xs0, ys0>, out[1] = <xs1, ys1> (either pair may be null to skip)
 int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
             host::Fr out[2]);
+int fr_dot2_launch(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m);  // on ctx->stream
+int fr_dot2_collect(halo_ctx *ctx, hipStream_t stream, size_t m, host::Fr out[2]);
 int fr_powers(halo_ctx *ctx, const host::Fr &z, size_t n, uint64_t *d_out);
 // d_v[i] *= a
 int fr_scale(halo_ctx *ctx, uint64_t *d_v, size_t n, const host::Fr &a);

@@ -702,9 +702,8 @@ static unsigned dot_blocks(size_t m) {
     if (nb == 0) nb = 1;
     return (unsigned)nb;
 }
-int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
-            host::Fr out[2]) {
-    out[0] = out[1] = host::Fr::zero();
+// the two halves of fr_dot2: launch (kernels + the copy of the two sums to pinned memory, on ctx->stream) and collect (wait)
+int fr_dot2_launch(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m) {
     if (m == 0) return HALO_OK;
     if (!xs0) { set_error("dot2: the first pair of vectors is required"); return HALO_E_ARG; }
     unsigned nb = dot_blocks(m);
@@ -714,10 +713,22 @@ int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint6
     HALO_LAUNCH(ctx, "k_sum_partials", k_sum_partials, dim3(1), dim3(256), 0, partial, nb, 2u, 1, partial + 8 * 1024);
     HALO_HIP(hipGetLastError());
     HALO_HIP(hipMemcpyAsync(ctx->h_pinned, partial + 8 * 1024, 64, hipMemcpyDeviceToHost, ctx->stream));
-    HALO_HIP(hipStreamSynchronize(ctx->stream));
+    return HALO_OK;
+}
+int fr_dot2_collect(halo_ctx *ctx, hipStream_t stream, size_t m, host::Fr out[2]) {
+    out[0] = out[1] = host::Fr::zero();
+    if (m == 0) return HALO_OK;
+    HALO_HIP(hipStreamSynchronize(stream));
     out[0] = host::Fr::load(ctx->h_pinned);
     out[1] = host::Fr::load(ctx->h_pinned + 4);
     return HALO_OK;
+}
+int fr_dot2(halo_ctx *ctx, const uint64_t *xs0, const uint64_t *ys0, const uint64_t *xs1, const uint64_t *ys1, size_t m,
+            host::Fr out[2]) {
+    out[0] = out[1] = host::Fr::zero();
+    int rc = fr_dot2_launch(ctx, xs0, ys0, xs1, ys1, m);
+    if (rc) return rc;
+    return fr_dot2_collect(ctx, ctx->stream, m, out);
 }
 
 // Window table of z (see window_power): 16 A-form entries, then nwin x 16 N-form entries, staged through pinned memory.
