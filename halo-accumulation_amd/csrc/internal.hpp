@@ -102,7 +102,7 @@ struct MsmWorkspace {
     uint32_t *d_presort = nullptr;   // the same entries grouped by bucket range only (two-level sort of large MSMs)
     uint32_t *d_buckets = nullptr;   // one native XYZZ partial (40 words) per task
     uint32_t *d_ntask = nullptr, *d_toff = nullptr, *d_tblockoff = nullptr, *d_biglist = nullptr, *d_meta = nullptr;
-    uint32_t *d_task_g = nullptr, *d_order = nullptr;  // per task: bucket | length bin << 24; tasks by decreasing length
+    uint32_t *d_task_g = nullptr, *d_order = nullptr;  // per task: bucket | length bin << 24; task records (4 words) by decreasing length
     uint16_t *d_fine16 = nullptr;    // table pipeline: low bucket bits beside d_presort (allocated on first use)
     uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)

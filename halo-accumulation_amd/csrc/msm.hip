@@ -945,8 +945,14 @@ __global__ __launch_bounds__(256) void k_msm_task_bins(const uint32_t *__restric
     __syncthreads();
     if (threadIdx.x <= KMAX && bins[threadIdx.x]) atomicAdd(&meta[2 + threadIdx.x], bins[threadIdx.x]);
 }
+// order[pos] = {task id, first entry of the task in `sorted`, its length, that first entry}: everything the bucket kernel
+// needs to start its gather, in ONE coalesced 16-byte load (it used to chase order -> task_g -> two scans + counts ->
+// sorted -> point: five dependent loads per task before the first addition)
 __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restrict__ task_g, uint32_t *__restrict__ meta,
-                                                        uint32_t *__restrict__ order) {
+                                                        const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ starts,
+                                                        const uint32_t *__restrict__ blockoff, const uint32_t *__restrict__ counts,
+                                                        const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
+                                                        uint32_t kmax, uint4 *__restrict__ order) {
     __shared__ uint32_t bins[KMAX + 1], base[KMAX + 1], tot[KMAX + 1];
     if (blockIdx.x * 256 >= meta[0]) return;
     if (threadIdx.x <= KMAX) {
@@ -957,9 +963,17 @@ __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restri
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     bool live = t < meta[0];
     uint32_t bin = 0, rank = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     if (live) {
-        bin = task_g[t] >> 24;
+        uint32_t tg = task_g[t];
+        bin = tg >> 24;
         rank = atomicAdd(&bins[bin], 1u);
+        uint32_t g = tg & 0xFFFFFFu;
+        uint32_t first = (t - scan_at(toff, tblockoff, g)) * kmax;
+        uint32_t cnt = counts[g] - first;
+        if (cnt > kmax) cnt = kmax;
+        uint32_t st = scan_at(starts, blockoff, g) + first;
+        rec = make_uint4(t, st, cnt, sorted[st]);
     }
     __syncthreads();
     if (threadIdx.x <= KMAX) {
@@ -968,34 +982,31 @@ __global__ __launch_bounds__(256) void k_msm_task_order(const uint32_t *__restri
         base[threadIdx.x] = start + (bins[threadIdx.x] ? atomicAdd(&meta[70 + threadIdx.x], bins[threadIdx.x]) : 0u);
     }
     __syncthreads();
-    if (live) order[base[bin] + rank] = t;
+    if (live) order[base[bin] + rank] = rec;
 }
 
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
-                                                        const uint32_t *__restrict__ starts, const uint32_t *__restrict__ blockoff,
-                                                        const uint32_t *__restrict__ counts, const uint32_t *__restrict__ toff,
-                                                        const uint32_t *__restrict__ tblockoff, const uint32_t *__restrict__ meta,
-                                                        const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_g,
-                                                        uint32_t kmax, uint32_t *__restrict__ partial) {
+                                                        const uint32_t *__restrict__ meta, const uint4 *__restrict__ order,
+                                                        uint32_t *__restrict__ partial) {
     uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     if (tid >= meta[0]) return;
-    uint32_t t = order[tid];
-    uint32_t g = task_g[t] & 0xFFFFFFu;
-    uint32_t first = (t - scan_at(toff, tblockoff, g)) * kmax;
-    uint32_t cnt = counts[g] - first;
-    if (cnt > kmax) cnt = kmax;
-    uint32_t st = scan_at(starts, blockoff, g) + first;
+    uint4 rec = order[tid];
+    uint32_t t = rec.x, st = rec.y, cnt = rec.z;
     XyzzN acc = xyzz_inf();
-    // the next point's index and coordinates are fetched before the current mixed add is issued, so the
-    // gather latency hides behind ~10k cycles of arithmetic even at two waves per SIMD
-    uint32_t e = sorted[st];
+    // the next point's coordinates are fetched before the current mixed add is issued, and ITS index one add earlier
+    // still: index -> gather is a dependent pair of loads, and with the index fetched in the same iteration the wave
+    // sat in s_waitcnt for a whole memory latency per addition (17 % of the kernel's wave cycles parked:
+    // profiles/r03_sq_msm.json).  The index load is unconditional, clamped to the task's last entry: a conditional one
+    // made the compiler wait for it -- and for the gather just issued -- at the end of the branch.
+    uint32_t e = rec.w;
+    uint32_t last = cnt - 1;
+    uint32_t e1 = sorted[st + (1 < last ? 1 : last)];
     AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
     for (uint32_t k = 0; k < cnt; k++) {
         AffN p = aff_cneg(nxt, (e >> 31) != 0);
-        if (k + 1 < cnt) {
-            e = sorted[st + k + 1];
-            nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
-        }
+        e = e1;
+        if (k + 1 < cnt) nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+        e1 = sorted[st + (k + 2 < last ? k + 2 : last)];
         xyzz_madd(acc, p);
     }
     xyzz_store(partial + XYZZ_WORDS * (size_t)t, acc);
@@ -1480,7 +1491,7 @@ static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) 
     HALO_HIP(hipMalloc(&ws.d_biglist, ws.cap_counts * 4));
     HALO_HIP(hipMalloc(&ws.d_meta, 1024));
     HALO_HIP(hipMalloc(&ws.d_task_g, ws.cap_tasks * 4));
-    HALO_HIP(hipMalloc(&ws.d_order, ws.cap_tasks * 4));
+    HALO_HIP(hipMalloc(&ws.d_order, ws.cap_tasks * 16));  // uint4 per task (k_msm_task_order)
     HALO_HIP(hipMalloc(&ws.d_seg, ws.cap_windows * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, ws.cap_windows * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8));
@@ -1804,9 +1815,10 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     size_t max_tasks = (size_t)total + entries / kmax + 1;
     if (max_tasks > ws.cap_tasks) max_tasks = ws.cap_tasks;
     dim3 gridt((unsigned)((max_tasks + 255) / 256));
-    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts, ws.d_toff,
-                ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
+                ws.d_toff, ws.d_tblockoff, kmax, reinterpret_cast<uint4 *>(ws.d_order));
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, ctx->d_table, ws.d_sorted, ws.d_meta, reinterpret_cast<const uint4 *>(ws.d_order),
+                ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 total, 512u, ws.d_buckets);
     // window sums: the buckets as tp.vw virtual windows of 2^vw_bits, 64 segments each (c = 20: 8 buckets per lane; c = 17: 1)
@@ -1916,9 +1928,10 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         HALO_LAUNCH(ctx, "k_msm_task_bins", k_msm_task_bins, gridt, b256, 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_counts, (uint32_t)total, kmax,
                     ws.d_meta, ws.d_task_g, ws.d_biglist);
     }
-    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_order);
-    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
-                ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_order, ws.d_task_g, kmax, ws.d_buckets);
+    HALO_LAUNCH(ctx, "k_msm_task_order", k_msm_task_order, gridt, b256, 0, ws.d_task_g, ws.d_meta, ws.d_sorted, ws.d_starts, ws.d_blockoff, ws.d_counts,
+                ws.d_toff, ws.d_tblockoff, kmax, reinterpret_cast<uint4 *>(ws.d_order));
+    HALO_LAUNCH(ctx, "k_msm_accumulate", k_msm_accumulate, gridt, b256, 0, d_bases, ws.d_sorted, ws.d_meta, reinterpret_cast<const uint4 *>(ws.d_order),
+                ws.d_buckets);
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 (uint32_t)total, 512u, ws.d_buckets);
     uint32_t L, nseg;

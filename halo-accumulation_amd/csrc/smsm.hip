@@ -270,14 +270,16 @@ __global__ __launch_bounds__(256) void k_smsm_accumulate(const uint32_t *__restr
     }
     XyzzN acc = xyzz_inf();
     if (cnt) {
+        // index two additions ahead, point one ahead (see k_msm_accumulate: the index -> gather pair is dependent)
         uint32_t e = sorted[st];
+        uint32_t last = cnt - 1;
+        uint32_t e1 = sorted[st + (1 < last ? 1 : last)];
         AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
         for (uint32_t k = 0; k < cnt; k++) {
             AffN p = aff_cneg(nxt, (e >> 31) != 0);
-            if (k + 1 < cnt) {
-                e = sorted[st + k + 1];
-                nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
-            }
+            e = e1;
+            if (k + 1 < cnt) nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+            e1 = sorted[st + (k + 2 < last ? k + 2 : last)];
             xyzz_madd(acc, p);
         }
     }
