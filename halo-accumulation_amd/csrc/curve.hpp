@@ -290,6 +290,15 @@ HALO_DEV void jac_store_words(uint64_t *o, const JacN &p) {
     }
     fe_store(o, fq_to_words(p.x)); fe_store(o + 4, fq_to_words(p.y)); fe_store(o + 8, fq_to_words(p.z));
 }
+// (X, Y, ZZ, ZZZ) -> Jacobian with Z = ZZZ: (X ZZ^2, Y ZZZ^2, ZZZ)   (ZZ^3 = ZZZ^2), as xyzz_store_jac_words
+HALO_DEV JacN xyzz_to_jac(const XyzzN &p) {
+    if (xyzz_is_inf(p)) return jac_inf();
+    JacN r;
+    r.x = fq_widen<8>(fq_mul(p.x, fq_sqr(p.zz)));
+    r.y = fq_widen<8>(fq_mul(p.y, fq_sqr(p.zzz)));
+    r.z = fq_widen<4>(p.zzz);
+    return r;
+}
 HALO_DEV XyzzN jac_to_xyzz(const JacN &p) {
     if (jac_is_inf(p)) return xyzz_inf();
     XyzzN r; r.x = p.x; r.y = p.y; r.zz = fq_sqr(p.z); r.zzz = fq_mul(r.zz, p.z); return r;

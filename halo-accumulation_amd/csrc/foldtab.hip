@@ -103,39 +103,61 @@ __global__ __launch_bounds__(256) void k_foldtab_build(const uint32_t *__restric
 // ---- the fold: six digit strings (k1, k2 of the three scalars; signed base 64, one byte per digit, four per word) are
 // kernel arguments: wave-uniform
 struct FoldDigits { uint32_t w[6][6]; };
+// `park` (36 words per thread, word k of thread t at park[256 k + t]) holds the plain accumulator while the lambda chain runs
 HALO_DEV JacN fold_one_tab(const uint32_t *__restrict__ G, const uint32_t *__restrict__ tab, uint32_t j, uint32_t m, uint32_t lo, uint32_t cnt,
-                           const FoldDigits &dg) {
+                           const FoldDigits &dg, uint32_t *park) {
     constexpr uint32_t BETA[9] = {0x1342a796, 0x3fdac51, 0x54dab11, 0x5b221a6, 0xccd27ac, 0x15cc87a4, 0x1b1533b6, 0x169e85e1, 0x3b0093};
     Fq<1> beta;
 #pragma unroll
     for (int i = 0; i < 9; i++) beta.v[i] = BETA[i];
-    JacN acc = jac_from_aff(aff_load(G + AFF_STRIDE * (size_t)j));
+    // XYZZ accumulators (mixed addition 8M + 2S against 7M + 4S in Jacobian form).  The entries of the three plain
+    // half-scalars are summed first, then those of the three lambda half-scalars AS THEY ARE into a second accumulator;
+    // lambda is applied once at the end, lambda (X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ): one product per output instead of
+    // one per addition.  Every branch depends only on kernel arguments (the digits), so a wave never diverges.
+    auto chain = [&](XyzzN &a, int lambda_half) {
 #pragma unroll 1
-    for (int word = 0; word < 6; word++) {
-        uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+        for (int word = 0; word < 6; word++) {
+            uint32_t d[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 6; q++) {  // (no runtime-indexed argument array: a select chain over scalar registers)
+            for (int q = 0; q < 6; q++) {  // (no runtime-indexed argument array: a select chain over scalar registers)
 #pragma unroll
-            for (int h = 0; h < 6; h++) d[h] = (q == word) ? dg.w[h][q] : d[h];
+                for (int h = 0; h < 3; h++) d[h] = (q == word) ? (lambda_half ? dg.w[2 * h + 1][q] : dg.w[2 * h][q]) : d[h];
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                int win = word * 4 + k;
+                if (win >= FT_WINDOWS) break;
+#pragma unroll 1
+                for (uint32_t t = 1; t <= 3; t++) {
+                    uint32_t packed = t == 1 ? d[0] : (t == 2 ? d[1] : d[2]);
+                    int dv = (int)(int8_t)((packed >> (8 * k)) & 0xffu);
+                    if (dv == 0) continue;  // wave-uniform
+                    uint32_t mag = (uint32_t)(dv < 0 ? -dv : dv);
+                    AffN e = ft_load(tab + ((size_t)(win * FT_MULT + (int)mag - 1) * cnt + (j + t * m - lo)) * FT_WORDS);
+                    xyzz_madd(a, aff_cneg(e, dv < 0));
+                }
+            }
         }
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            int win = word * 4 + k;
-            if (win >= FT_WINDOWS) break;
-            auto step = [&](uint32_t packed, uint32_t t, bool lambda_half) {
-                int dv = (int)(int8_t)((packed >> (8 * k)) & 0xffu);
-                if (dv == 0) return;  // wave-uniform
-                uint32_t mag = (uint32_t)(dv < 0 ? -dv : dv);
-                AffN e = ft_load(tab + ((size_t)(win * FT_MULT + (int)mag - 1) * cnt + (j + t * m - lo)) * FT_WORDS);
-                if (lambda_half && !aff_is_inf(e)) e.x = fq_mul(e.x, beta);  // lambda (x, y) = (beta x, y)
-                acc = jac_madd(acc, aff_cneg(e, dv < 0));
-            };
-            step(d[0], 1, false); step(d[1], 1, true);
-            step(d[2], 2, false); step(d[3], 2, true);
-            step(d[4], 3, false); step(d[5], 3, true);
+    };
+    uint32_t *mine = park + threadIdx.x;
+    {
+        XyzzN acc = xyzz_from_aff(aff_load(G + AFF_STRIDE * (size_t)j));
+        chain(acc, 0);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            mine[256 * k] = acc.x.v[k]; mine[256 * (9 + k)] = acc.y.v[k]; mine[256 * (18 + k)] = acc.zz.v[k]; mine[256 * (27 + k)] = acc.zzz.v[k];
         }
     }
-    return acc;
+    XyzzN accl = xyzz_inf();
+    chain(accl, 1);
+    if (!xyzz_is_inf(accl)) accl.x = fq_widen<8>(fq_mul(accl.x, beta));
+    XyzzN acc;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc.x.v[k] = mine[256 * k]; acc.y.v[k] = mine[256 * (9 + k)]; acc.zz.v[k] = mine[256 * (18 + k)]; acc.zzz.v[k] = mine[256 * (27 + k)];
+    }
+    xyzz_add(acc, accl);
+    return xyzz_to_jac(acc);
 }
 // as k_fold_points4: a lane folds j and j + half and shares one inversion; src (the key) and dst are different arrays
 __global__ __launch_bounds__(256, 2) void k_fold_tab4(const uint32_t *__restrict__ G, const uint32_t *__restrict__ tab, uint32_t *__restrict__ out,
@@ -143,9 +165,22 @@ __global__ __launch_bounds__(256, 2) void k_fold_tab4(const uint32_t *__restrict
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= half) return;
     bool two = j + half < m;
+    // the first result waits in LDS while the second chain runs (two XYZZ accumulators + an entry + a mixed addition's
+    // temporaries fill the 256 registers that two waves per SIMD allow); word k of thread t at park[256 k + t]
+    __shared__ uint32_t park[27 * 256], park_acc[36 * 256];
     JacN p[2];
-    p[0] = fold_one_tab(G, tab, j, m, lo, cnt, dg);
-    p[1] = two ? fold_one_tab(G, tab, j + half, m, lo, cnt, dg) : jac_inf();
+    {
+        JacN r0 = fold_one_tab(G, tab, j, m, lo, cnt, dg, park_acc);
+        uint32_t *mine = park + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { mine[256 * k] = r0.x.v[k]; mine[256 * (9 + k)] = r0.y.v[k]; mine[256 * (18 + k)] = r0.z.v[k]; }
+    }
+    p[1] = two ? fold_one_tab(G, tab, j + half, m, lo, cnt, dg, park_acc) : jac_inf();
+    {
+        const uint32_t *mine = park + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { p[0].x.v[k] = mine[256 * k]; p[0].y.v[k] = mine[256 * (9 + k)]; p[0].z.v[k] = mine[256 * (18 + k)]; }
+    }
     AffN a[2];
     jac_batch_to_aff(p, a);
     aff_store(out + AFF_STRIDE * (size_t)j, a[0]);
