@@ -278,6 +278,16 @@ def main():
             wave_mads = batch * shard_pts * plan_w / parts * 1143 / 64
             peak = props.multi_processor_count * 4 * 2.4e9 / 5.26  # 2.40 GHz engine clock (the microbenchmark's reading)
             valu = {"unit": "v_mad_u64_u32 wave-instr/s", "achieved": wave_mads / kern_s, "peak": peak, "frac": wave_mads / kern_s / peak}
+            # what the SIMDs did during the kernel, from the committed SQ counter pass (static, like `traffic`): vector
+            # instructions issued per 4-cycle issue slot over all 1024 SIMDs, the clock the chip held, parked wave cycles
+            sq = os.path.join(ROOT, "profiles", "r03_sq_msm.json")
+            if world == 1 and args.log_n == 20 and os.path.exists(sq):
+                k = json.load(open(sq))["kernels"].get(dom)
+                if k:
+                    valu["issue_slots_used"] = k["valu_per_quad"]
+                    valu["clock_ghz_during_kernel"] = k["clock_ghz"]
+                    valu["wave_cycles_parked"] = k["wave_parked"]
+                    valu["issue_source"] = "static: profiles/r03_sq_msm.json (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_ANY ..., one MSM in flight)"
         result = {
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
             "value": args.steps / dt, "unit": "MSM/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,

@@ -25,6 +25,7 @@ stats("prof_open", "open_check_kernel_stats.csv")
 stats("fr_trace", "fr_kernels_kernel_stats.csv")
 cp(os.path.join(ev, "open_timeline.txt"), "open_check_timeline.txt")
 cp(os.path.join(ev, "pmc_traffic.json"), "pmc_traffic.json")
+cp(os.path.join(ev, "sq_msm.json"), "sq_msm.json")
 cp(os.path.join(ev, "pmc_fr.json"), "pmc_open.json")
 cp(os.path.join(ev, "fr_kernels_events.json"), "fr_kernels_events.json")
 cp(os.path.join(ev, "pmc_open_kernels.json"), "pmc_open_loop.json")

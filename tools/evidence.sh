@@ -17,6 +17,9 @@ python tools/trace_timeline.py $(find $OUT/prof_open -name "*kernel_trace.csv" |
 step pmc_fetch; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_fetch.log 2>&1 || exit 1
 step pmc_write; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_write.log 2>&1 || exit 1
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json || exit 1
+# what the SIMDs do during the integer kernels: issue slots used, clock held, parked wave cycles (tools/sq_summary.py)
+step pmc_sq; timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_sq.log 2>&1 || exit 1
+python tools/sq_summary.py $OUT/pmc_sq > $OUT/sq_msm.json || exit 1
 # the bandwidth-side Fr kernels alone (K4-K9): steady-state durations and HBM-side bytes, each launch back to back
 step fr_trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fr_trace -- python3 tools/fr_kernels.py 20 20 > $OUT/fr_trace.log 2>&1 || exit 1
 step fr_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fr_fetch -- python3 tools/fr_kernels.py 20 6 > $OUT/fr_fetch.log 2>&1 || exit 1
