@@ -489,6 +489,52 @@ def main():
             t_dec = time.perf_counter() - t0
             result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_chain / args.asdl_steps * 1e3,
                                     "verifier_ms_each": t_ver / args.asdl_steps * 1e3, "decider_ms": t_dec * 1e3, "all_accepted": True}
+    if world > 1 and args.open_steps > 0 and world & (world - 1) == 0 and n % world == 0:
+        # BASELINE configs[2] on N GPUs: pcdl::open + check with the key, the coefficients and the z-powers placed cyclically
+        # (element i on rank i mod N; sharded.ShardedOpen): per round one all-gather of 256 B per rank, no vector exchange;
+        # the check's commitment to h is sharded the same way (halo_pcdl_check_partial).  The same polynomial as at N = 1
+        # (seed ...03); a rank's coefficients c[r::N] are handed over in host memory at every open.
+        from halo_accumulation_amd.sharded import ShardedOpen, make_allgather
+        ag = make_allgather(coll_dev)
+        so = ShardedOpen(h._lib, rank, world, ag, device=gpu)
+        sctx = so.load_key(n)
+        sctx.set_fold_table(1)  # the comb table of the first fold over this rank's shard, built at the first (warm-up) open
+        d_co = torch.empty((n + 2) * 4, dtype=torch.int64, device=dev)
+        sctx.rng_scalars_dev(0x48414C4F00000003, n + 2, d_co.data_ptr())
+        co = d_co.cpu().numpy().view(np.uint64).reshape(n + 2, 4)
+        c_local, z_open = np.ascontiguousarray(co[:n][rank::world]), np.ascontiguousarray(co[n])
+        del d_co
+        C = h._lib.point_sum(ag(sctx.msm(c_local)))  # pcdl::commit, non-hiding: the sum of the ranks' MSMs
+        for _ in range(2):
+            pi, v_open = so.open(c_local, C, z_open)
+            so.check(C, n - 1, z_open, v_open, pi)
+        ts = []
+        for _ in range(args.open_steps):
+            dist.barrier()
+            t0 = time.perf_counter()
+            pi, v_open = so.open(c_local, C, z_open)
+            so.check(C, n - 1, z_open, v_open, pi)
+            ts.append(time.perf_counter() - t0)
+        tmax = torch.tensor(ts, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ts = sorted(tmax.cpu().tolist())
+        if rank == 0:
+            odt = ts[len(ts) // 2]
+            # the sharded proof must be the single-GPU proof: the same open on this rank's GPU alone
+            full_o = h._lib.Context(urs_n=n, first_index=2, device=gpu)
+            coeffs_all = np.ascontiguousarray(co[:n])
+            assert C.tolist() == pcdl.commit(full_o, coeffs_all, n - 1).tolist(), "sharded commitment differs"
+            want = pcdl.open(full_o, [1], coeffs_all, C, n - 1, z_open)
+            same = want.tolist() == pi.tolist()
+            pcdl.check_proof(full_o, C, n - 1, z_open, v_open, pi)
+            full_o.close()
+            result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False, "ranks": world,
+                                         "samples_ms": [round(x * 1e3, 3) for x in ts], "proof_equals_single_gpu": same,
+                                         "note": "sharded.ShardedOpen: cyclic shards of G, c, z-powers; per round one all-gather of 256 B per "
+                                                 "rank; check = succinct check on every rank + sharded commitment to h; max over ranks "
+                                                 "per repetition, median reported; coefficients handed over in host memory"}
+            assert same, "sharded open differs from the single-GPU open"
+        so.ctx.close()
     if world > 1 and rank == 0:
         # cross-check of the sharded results: the same MSMs, unsharded, on this rank's GPU alone
         full = ctx if window_mode else h._lib.Context(urs_n=n, first_index=2, device=gpu)

@@ -77,6 +77,7 @@ _SIGS = {
     "halo_open_hiding_combine": (C.c_int, [u64p, u64p, u64p, u64p, C.c_size_t, u64p, C.POINTER(C.c_uint64), C.c_size_t, u64p, u64p, u64p, u64p]),
     "halo_open_start": (C.c_int, [u64p, u64p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_open_combine": (C.c_int, [u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]),
+    "halo_open_tail": (C.c_int, [u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]),
     "halo_ipa_round_lr": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "halo_ipa_round_fold": (C.c_int, [C.c_void_p, u64p, u64p]),
     "halo_ipa_finish": (C.c_int, [C.c_void_p, u64p, u64p]),
@@ -95,6 +96,7 @@ _SIGS = {
     "halo_pcdl_succinct_check_batch": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
     "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "halo_pcdl_check_partial": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u64p, u64p]),
     "halo_acc_prover": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_verifier": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_decider": (C.c_int, [C.c_void_p, u64p]),
@@ -531,6 +533,18 @@ def open_combine(parts, Hp, xi_prev):
     check(load().halo_open_combine(ptr(parts), parts.shape[0], ptr(np.ascontiguousarray(Hp, dtype=np.uint64)),
                                    ptr(np.ascontiguousarray(xi_prev, dtype=np.uint64)), ptr(L), ptr(R), ptr(xi), ptr(xi_inv)))
     return L, R, xi, xi_inv
+
+
+def open_tail(recs, Hp, xi_prev):
+    """recs (P, 20): the gathered (G_i | c_i | z_i) in index order -> (Ls (lg P, 12), Rs (lg P, 12), U, c): the last lg P rounds on the host"""
+    recs = np.ascontiguousarray(recs, dtype=np.uint64).reshape(-1, 20)
+    P = recs.shape[0]
+    lg = max(P.bit_length() - 1, 0)
+    Ls, Rs = np.zeros((max(lg, 1), 12), dtype=np.uint64), np.zeros((max(lg, 1), 12), dtype=np.uint64)
+    U, c = np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    check(load().halo_open_tail(ptr(recs), P, ptr(np.ascontiguousarray(Hp, dtype=np.uint64)), ptr(np.ascontiguousarray(xi_prev, dtype=np.uint64)),
+                                ptr(Ls), ptr(Rs), ptr(U), ptr(c)))
+    return Ls[:lg], Rs[:lg], U, c
 
 
 def _encode(fn, blob, cap):

@@ -1028,6 +1028,56 @@ int halo_open_combine(const uint64_t *parts, size_t P, const uint64_t Hp[12], co
     return HALO_OK;
 }
 
+// The last lg P rounds of a sharded open (pcdl.rs:195-227 over the P gathered elements, P <= 64): host arithmetic only --
+// a launch sequence per round for a handful of points is all latency, and the throw-away context the Python driver used to
+// build for these rounds cost more to create and destroy than the rounds themselves.
+int halo_open_tail(const uint64_t *recs, size_t P, const uint64_t Hp[12], const uint64_t xi_prev[4], uint64_t *Ls, uint64_t *Rs,
+                   uint64_t U[12], uint64_t c_out[4]) {
+    if (!recs || !Hp || !xi_prev || !U || !c_out || P == 0 || (P & (P - 1)) != 0 || P > 64 || (P > 1 && (!Ls || !Rs))) {
+        set_error("open_tail: P must be a power of two of at most 64 elements, no null pointers");
+        return HALO_E_ARG;
+    }
+    std::vector<host::Point> G(P);
+    std::vector<host::Fr> c(P), z(P);
+    for (size_t i = 0; i < P; ++i) {
+        const uint64_t *r = recs + 20 * i;  // G_i (Jacobian, 12 words) | c_i | z_i
+        G[i] = host::Point::load(r);
+        c[i] = host::Fr::load(r + 12);
+        z[i] = host::Fr::load(r + 16);
+    }
+    host::Point H = host::Point::load(Hp);
+    host::Fr xi = host::Fr::load(xi_prev);
+    size_t round = 0;
+    for (size_t m = P / 2; m >= 1; m /= 2, ++round) {
+        host::Point L = host::Point::infinity(), R = host::Point::infinity();
+        host::Fr dl = host::Fr::zero(), dr = host::Fr::zero();
+        for (size_t j = 0; j < m; ++j) {
+            L = L + G[j].mul(c[m + j]);      // <c_r, G_l>   (:204)
+            R = R + G[m + j].mul(c[j]);      // <c_l, G_r>   (:208)
+            dl = dl + c[m + j] * z[j];       // <c_r, z_l>   (:203)
+            dr = dr + c[j] * z[m + j];       // <c_l, z_r>   (:207)
+        }
+        L = (L + H.mul(dl)).normalized();
+        R = (R + H.mul(dr)).normalized();
+        host::Transcript t;
+        t.scalar(xi); t.point(L); t.point(R);
+        host::Fr x = t.finish(0);  // :212
+        if (x.is_zero()) { set_error("open: challenge is zero (inverse().unwrap())"); return HALO_E_ASSERT; }
+        host::Fr xinv = x.inv();
+        L.store(Ls + 12 * round);
+        R.store(Rs + 12 * round);
+        for (size_t j = 0; j < m; ++j) {
+            G[j] = G[j] + G[m + j].mul(x);   // :218
+            c[j] = c[j] + xinv * c[m + j];   // :222
+            z[j] = z[j] + x * z[m + j];      // :223
+        }
+        xi = x;
+    }
+    G[0].store_normalized(U);  // :230
+    c[0].store(c_out);
+    return HALO_OK;
+}
+
 int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n_out) {
     if (!xi || !out || !n_out) { set_error("glv_digits: null pointer"); return HALO_E_ARG; }
     host::GlvDigits dg = host::glv_digits(host::Fr::load(xi));

@@ -191,12 +191,13 @@ struct SuccinctState {
     Point C_prime, Hp, U;
     std::vector<Fr> xis;
 };
+// key_n: the size of the key the check is against (ctx->n; a rank's cyclic shard stands for stride * ctx->n points)
 static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof_c, SuccinctState *st,
-                               bool need_hp = true) {
+                               bool need_hp = true, size_t key_n = 0) {
     uint64_t *proof = const_cast<uint64_t *>(proof_c);
     size_t n = d + 1;
     if (!is_pow2(n)) return fail_reject("d+1 is not a power of 2!");
-    if (d + 1 > ctx->n) return fail_reject("d was larger than D!");
+    if (d + 1 > (key_n ? key_n : ctx->n)) return fail_reject("d was larger than D!");
     size_t lg_n = ilog2(n);
     if (proof[1] != lg_n) return fail_reject("proof length does not match d");
     // Everything below reads exactly proof_words(lg_n) words.  The blob is verifier input: the reference's typed
@@ -384,6 +385,40 @@ static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z,
     if (rc_rel) { set_error(rel_err); return rc_rel; }
     if (rc) return rc;
     if (st.U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339
+    return HALO_OK;
+}
+
+// One rank's half of pcdl::check when the key is sharded cyclically (point i on rank i mod P): the succinct check (host
+// arithmetic, the same on every rank) and this rank's share of CM.Commit(ck, h) (:338).  The coefficient of X^(r + j P) is
+//     prod_{i < p, bit i of r} xi_(lg n - i)  *  prod_{bit i' of j} xi_(lg n - p - i')            (P = 2^p, pcdl.rs:56-77)
+// i.e. a constant of the rank times the j-th coefficient of the h polynomial of the first lg n - p challenges: the shard's
+// scalars are h_coeffs_dev over lg n - p variables scaled by that constant.  The caller adds the P shares and compares
+// with U (:339).
+static int pcdl_check_partial_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof, uint64_t stride,
+                                   uint64_t offset, Point *U_out, Point *part_out) {
+    if (stride == 0 || !is_pow2(stride) || offset >= stride) { set_error("check_partial: stride must be a power of two, offset below it"); return HALO_E_ARG; }
+    if (ctx->n == 0 || !is_pow2(ctx->n)) { set_error("check_partial: the shard's key must hold a power of two of points"); return HALO_E_ARG; }
+    SuccinctState st;
+    int rc = succinct_challenges(ctx, C, d, z, v, proof, &st, true, ctx->n * stride);
+    if (rc) return rc;
+    size_t lg_n = st.lg_n, n = d + 1, p = ilog2((size_t)stride);
+    if (n < stride) { set_error("check_partial: fewer coefficients than ranks"); return HALO_E_ARG; }
+    size_t n_local = n / stride;  // <= ctx->n
+    Fr scale = Fr::one();
+    for (size_t i = 0; i < p; ++i)
+        if ((offset >> i) & 1) scale = scale * st.xis[lg_n - i];
+    rc = h_coeffs_dev(ctx, st.xis.data(), lg_n - p, scale, false, ctx->d_tmp_a);
+    if (rc) return rc;
+    rc = msm_enqueue(ctx, 0, ctx->d_bases, ctx->d_tmp_a, true, n_local);  // asynchronous: the relation runs on the host meanwhile
+    if (rc) return rc;
+    int rc_rel = succinct_relation(st, z, v, proof);
+    std::string rel_err = rc_rel ? halo_last_error() : "";
+    Point part;
+    rc = msm_finish(ctx, 0, &part);
+    if (rc_rel) { set_error(rel_err); return rc_rel; }
+    if (rc) return rc;
+    *U_out = st.U;
+    *part_out = part;
     return HALO_OK;
 }
 
@@ -644,6 +679,18 @@ int halo_pcdl_succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *inst
 int halo_pcdl_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof) {
     HALO_CTX2(ctx);
     return pcdl_check_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof);
+}
+
+int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof,
+                            uint64_t stride, uint64_t offset, uint64_t U_out[12], uint64_t part_out[12]) {
+    HALO_CTX2(ctx);
+    if (!C || !z || !v || !proof || !U_out || !part_out) { set_error("check_partial: null pointer"); return HALO_E_ARG; }
+    Point U, part;
+    int rc = pcdl_check_partial_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof, stride, offset, &U, &part);
+    if (rc) return rc;
+    U.store_normalized(U_out);
+    part.store_normalized(part_out);
+    return HALO_OK;
 }
 
 // acc.rs:190-220

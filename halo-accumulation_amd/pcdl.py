@@ -84,6 +84,14 @@ def check_proof(ctx, Cm, d, z, v, pi):
     check(ctx.lib.halo_pcdl_check(ctx.h, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(v)), ptr(_a(pi))))
 
 
+def check_partial(ctx, Cm, d, z, v, pi, stride, offset):
+    """One rank's half of pcdl::check over a cyclically sharded key (halo_pcdl_check_partial): -> (U, this rank's share of
+    CM.Commit(ck, h)).  The caller adds the shares in rank order and accepts iff the sum is U (sharded.ShardedOpen.check)."""
+    U, part = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+    check(ctx.lib.halo_pcdl_check_partial(ctx.h, ptr(_a(Cm)), d, ptr(_a(z)), ptr(_a(v)), ptr(_a(pi)), stride, offset, ptr(U), ptr(part)))
+    return U, part
+
+
 class HPoly:
     """pcdl.rs:44-92"""
 

@@ -105,6 +105,34 @@ class ShardedMsm:
         return self.sum_fn(pts)
 
 
+def make_allgather(device=None):
+    """allgather(arr: uint64 ndarray) -> (P, len(arr)) uint64 over torch.distributed (RCCL when `device` is the rank's GPU,
+    gloo with device=None/cpu): what ShardedOpen takes.  The staging buffers of a message size are allocated once."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    bufs = {}
+
+    def allgather(arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+        k = a.size
+        if k not in bufs:
+            host = torch.empty(k, dtype=torch.int64)
+            if dev.type != "cpu":
+                host = host.pin_memory()
+            bufs[k] = (host, host if dev.type == "cpu" else torch.empty(k, dtype=torch.int64, device=dev),
+                       torch.empty(world * k, dtype=torch.int64, device=dev))
+        host, send, recv = bufs[k]
+        host.numpy()[:] = a.view(np.int64)
+        if send is not host:
+            send.copy_(host, non_blocking=True)
+        dist.all_gather_into_tensor(recv, send)
+        return recv.cpu().numpy().view(np.uint64).reshape(world, k)
+
+    return allgather
+
+
 # Fq Montgomery one: the X, Y of the library's normalised point at infinity (1, 1, 0)
 _FQ_ONE = np.array([0x34786D38FFFFFFFD, 0x992C350BE41914AD, 0xFFFFFFFFFFFFFFFF, 0x3FFFFFFFFFFFFFFF], dtype=np.uint64)
 
@@ -132,6 +160,18 @@ class ShardedOpen:
         self.n = n
         self.ctx = self.lib.Context(urs_n=n // self.world, first_index=first_index + self.rank, stride=self.world, device=self.device)
         return self.ctx
+
+    def check(self, Cm, d, z, v, proof):
+        """pcdl::check (pcdl.rs:323-342) against the sharded key: every rank runs the succinct check (host arithmetic) and
+        commits to its own share of h's coefficients over its own points; one all-gather of 96 bytes per rank, the shares
+        added in rank order, U compared (:339).  Raises HaloReject like pcdl.check_proof, on every rank alike."""
+        from . import pcdl
+        from ._lib import HaloReject, point_sum
+        U, part = pcdl.check_partial(self.ctx, Cm, d, z, v, proof, self.world, self.rank)
+        parts = self.allgather(part) if self.world > 1 else part[None]
+        comm = point_sum(parts)
+        if comm.tolist() != U.tolist():  # both normalised: (x, y, 1) or (1, 1, 0)
+            raise HaloReject("U != CM.Commit(ck, h_vec)")
 
     def _rounds(self, ipa, count, Hp, xi, Ls, Rs, world):
         for _ in range(count):
@@ -169,16 +209,9 @@ class ShardedOpen:
         ipa.close()
         if P > 1:
             rec = self.allgather(np.concatenate([U, c, z0]))  # (P, 20): the P remaining elements in index order
-            bases = np.zeros((P, 8), dtype=np.uint64)
-            for i in range(P):
-                if rec[i, 8:12].any():  # Z = 1: normalised affine; Z = 0: infinity stays (0, 0)
-                    bases[i] = rec[i, :8]
-            small = self.lib.Context(bases, device=self.device)
-            ipa2 = self.lib.Ipa(small, P, np.ascontiguousarray(rec[:, 12:16]), None, z_vec=np.ascontiguousarray(rec[:, 16:20]))
-            self._rounds(ipa2, P.bit_length() - 1, Hp, xi, Ls, Rs, 1)
-            U, c = ipa2.finish()
-            ipa2.close()
-            small.close()
+            tL, tR, U, c = self.lib.open_tail(rec, Hp, xi)  # the last lg P rounds: host arithmetic, the same on every rank
+            Ls.extend(tL)
+            Rs.extend(tR)
         proof = np.zeros(self.lib.load().halo_proof_words(lg_n), dtype=np.uint64)
         proof[1] = lg_n
         for i in range(lg_n):

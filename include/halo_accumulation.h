@@ -169,6 +169,12 @@ int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v
  * challenge rho_0(xi_prev, L, R) and its inverse (pcdl.rs:203-213) */
 int halo_open_combine(const uint64_t *parts, size_t P, const uint64_t Hp[12], const uint64_t xi_prev[4], uint64_t L[12], uint64_t R[12],
                       uint64_t xi[4], uint64_t xi_inv[4]);
+/* the last lg P rounds of a sharded open, on the host: after lg(n / P) rounds every rank holds ONE element of G, c and z;
+ * recs = the P gathered records (G_i Jacobian 12 | c_i 4 | z_i 4) in index order, P a power of two <= 64.  Runs pcdl.rs:195-227
+ * over them (challenges chained from xi_prev) and returns the lg P pairs L, R (12 words each, round order), U and c
+ * (pcdl.rs:230-231).  Identical on every rank. */
+int halo_open_tail(const uint64_t *recs, size_t P, const uint64_t Hp[12], const uint64_t xi_prev[4], uint64_t *Ls, uint64_t *Rs,
+                   uint64_t U[12], uint64_t c_out[4]);
 /* L = <c_r, G_l> + <c_r, z_l> H', R = <c_l, G_r> + <c_l, z_r> H'   (pcdl.rs:203-208) */
 int halo_ipa_round_lr(halo_ipa *st, const uint64_t H_prime[12], uint64_t L[12], uint64_t R[12]);
 /* G, c, z folds with the challenge the host hashed from (xi_prev, L, R)   (pcdl.rs:216-224) */
@@ -218,6 +224,13 @@ int halo_pcdl_succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *inst
                                    int *status);
 /* pcdl::check (pcdl.rs:323-342) */
 int halo_pcdl_check(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof);
+/* One rank's half of pcdl::check over a key sharded cyclically (halo_ctx_create_urs_strided: point i on rank i mod stride,
+ * offset = the rank): the succinct check (pcdl.rs:333, the same on every rank; d + 1 may be up to stride * the shard's size)
+ * and this rank's share of CM.Commit(ck, h) (pcdl.rs:338) over its own points.  U_out = the proof's U after the succinct
+ * check, part_out = the share.  The caller adds the shares of all ranks in rank order (halo_point_sum) and accepts iff the
+ * sum equals U (pcdl.rs:339); errors as halo_pcdl_check. */
+int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4], const uint64_t *proof,
+                            uint64_t stride, uint64_t offset, uint64_t U_out[12], uint64_t part_out[12]);
 /* acc::prover / verifier / decider (acc.rs:190-255); instances = m contiguous Instance blobs */
 int halo_acc_prover(halo_ctx *ctx, uint64_t *rng_state, size_t d, const uint64_t *instances, size_t m, uint64_t *acc_out);
 int halo_acc_verifier(halo_ctx *ctx, size_t d, const uint64_t *instances, size_t m, const uint64_t *acc);

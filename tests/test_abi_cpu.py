@@ -136,3 +136,40 @@ def test_fold_comb_digits_host(hal):
         k2 = sum(int(out[22 + i]) << (6 * i) for i in range(22))
         assert abs(k1) < 1 << 129 and abs(k2) < 1 << 129
         assert (k1 + k2 * lam - x) % pm.R_ORDER == 0
+
+
+def test_open_tail_reproduces_a_whole_open(hal):
+    """halo_open_tail runs pcdl.rs:195-227 on the host over P gathered (G_i, c_i, z_i): fed the WHOLE state of an 8-point
+    open (G = the key, c = the coefficients, z_i = z^i) it must return every L, R, U and c of the oracle's proof."""
+    from halo_accumulation_amd.sharded import _FQ_ONE
+    n, lg = 8, 3
+    gs = orc.urs_affine(2, n)
+    pp = orc.make_pp(gs)
+    coeffs, s = orc.rng_scalars(0xC0FFEE, n)
+    zz, _ = orc.rng_scalars(s, 1)
+    z = zz[0]
+    Cj = orc.pcdl_commit(pp, coeffs, n - 1)
+    proof, _ = orc.pcdl_open(pp, 1, coeffs, Cj, n - 1, z)
+    v = orc.poly_eval(coeffs, z)
+    v2, xi0, Hp = hal._lib.open_start(Cj, z, np.asarray(v).reshape(1, 4))
+    assert v2.tolist() == np.asarray(v).tolist()
+    recs = np.zeros((n, 20), dtype=np.uint64)
+    recs[:, :8] = np.asarray(gs).reshape(n, 8)
+    recs[:, 8:12] = _FQ_ONE
+    recs[:, 12:16] = coeffs
+    recs[:, 16:20] = orc.powers(z, n)
+    Ls, Rs, U, c = hal._lib.open_tail(recs, Hp, xi0)
+    for i in range(lg):
+        assert Ls[i].tolist() == proof[2 + 12 * i: 14 + 12 * i].tolist()
+        assert Rs[i].tolist() == proof[2 + 12 * lg + 12 * i: 14 + 12 * lg + 12 * i].tolist()
+    o = 2 + 24 * lg
+    assert U.tolist() == proof[o: o + 12].tolist() and c.tolist() == proof[o + 12: o + 16].tolist()
+    # one element: no round, U = G_0 and c = c_0
+    Ls, Rs, U, c = hal._lib.open_tail(recs[:1], Hp, xi0)
+    assert len(Ls) == 0 and U.tolist() == recs[0, :12].tolist() and c.tolist() == coeffs[0].tolist()
+    # an infinity among the points (Z = 0) is folded like any other point
+    inf = recs.copy(); inf[5, :12] = 0; inf[5, 0:4] = _FQ_ONE; inf[5, 4:8] = _FQ_ONE
+    hal._lib.open_tail(inf, Hp, xi0)
+    for bad in (3, 0, 128):
+        with pytest.raises(hal._lib.HaloError):
+            hal._lib.open_tail(np.zeros((bad, 20), dtype=np.uint64) if bad else np.zeros((0, 20), dtype=np.uint64), Hp, xi0)

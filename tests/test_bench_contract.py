@@ -45,6 +45,26 @@ def test_bench_emits_contract_json():
     assert all(v["achieved"] > 0 and abs(v["frac"] - v["achieved"] / 8000.0) < 1e-12 for v in hk.values())
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_report_msms_and_the_sharded_open():
+    """N = 2 as the driver launches it (one process per rank; gloo so that both ranks can share the one GPU of the test box):
+    one JSON line from rank 0 with the whole-job MSM rate and open + check over the cyclically sharded key, whose proof the
+    bench itself compares with the single-GPU open."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HALO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--steps", "8", "--warmup", "2",
+                          "--open-steps", "2", "--min-seconds", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["sharded_equals_single_gpu"] is True
+    oc = r["pcdl_open_check"]
+    assert oc["ranks"] == 2 and oc["value"] > 0 and oc["proof_equals_single_gpu"] is True and len(oc["samples_ms"]) == 2
+
+
 def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head, _, tail = src.partition("if args.cpu_msms > 0:")

@@ -642,6 +642,16 @@ def _sharded_worker(rank, world, port, n, q):
         C = Cs.numpy().view(np.uint64)
         rng = [4242]
         proof, v = so.open(np.ascontiguousarray(full[rank::world]), C, z[0], w=w, rng=rng, deg=n - 4)
+        # pcdl::check against the sharded key: accepted by every rank; a proof with another U is rejected by every rank
+        so.check(C, n - 1, z[0], v, proof)
+        bad = proof.copy()
+        lg = n.bit_length() - 1
+        bad[2 + 24 * lg: 14 + 24 * lg] = proof[2:14]  # U := L_0 (a valid point, the wrong one)
+        try:
+            so.check(C, n - 1, z[0], v, bad)
+            ok = False
+        except ValueError:
+            pass
         if rank == 0:
             ok = ok and proof.tolist() == want.tolist() and rng[0] == rng_ref[0]
             pcdl.check_proof(ref, C, n - 1, z[0], v, proof)
@@ -690,3 +700,40 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     r1, r2 = [77], [77]
     proof, _ = so.open(coeffs, Ch, z[0], w=w[0], rng=r1, deg=n - 1)
     assert proof.tolist() == pcdl.open(ctx, r2, coeffs, Ch, n - 1, z[0], w[0]).tolist() and r1 == r2
+    so.check(Ch, n - 1, z[0], v, proof)  # world 1: the whole of pcdl::check
+
+
+def test_check_partial_shares_add_up_to_the_commitment_of_h(hal):
+    """halo_pcdl_check_partial on the P cyclic shards of a key (all on this one GPU): every rank returns the proof's U,
+    and the P shares add up to CM.Commit(ck, h) = U (pcdl.rs:338-339) -- P = 1, 2, 8, and P = n (one point per rank)."""
+    from halo_accumulation_amd import pcdl
+    n = 64
+    full = hal._lib.Context(urs_n=n)
+    coeffs, s = orc.rng_scalars(404, n)
+    z, _ = orc.rng_scalars(s, 1)
+    C = pcdl.commit(full, coeffs, n - 1)
+    proof = pcdl.open(full, [9], coeffs, C, n - 1, z[0])
+    v = full.poly_eval(coeffs, z[0])
+    xis, U = pcdl.succinct_check(full, C, n - 1, z[0], v, proof)
+    hc = pcdl.HPoly(full, xis).get_poly()
+    for P in (1, 2, 8, n):
+        parts = []
+        for r in range(P):
+            sh = hal._lib.Context(urs_n=n // P, first_index=2 + r, stride=P)
+            Ur, part = pcdl.check_partial(sh, C, n - 1, z[0], v, proof, P, r)
+            assert Ur.tolist() == np.asarray(U).tolist()
+            # the share is the MSM of the coefficients r, r + P, ... over the rank's points
+            assert part.tolist() == sh.msm(np.ascontiguousarray(hc[r::P])).tolist()
+            parts.append(part)
+            sh.close()
+        assert hal._lib.point_sum(np.stack(parts)).tolist() == np.asarray(U).tolist()
+    # argument errors and the size rule: d + 1 may be up to stride * shard size, not more
+    sh = hal._lib.Context(urs_n=n // 4, first_index=2, stride=4)
+    with pytest.raises(hal._lib.HaloError):
+        pcdl.check_partial(sh, C, n - 1, z[0], v, proof, 3, 0)
+    with pytest.raises(hal._lib.HaloError):
+        pcdl.check_partial(sh, C, n - 1, z[0], v, proof, 4, 4)
+    with pytest.raises(ValueError):
+        pcdl.check_partial(sh, C, n - 1, z[0], v, proof, 2, 0)  # 2 * 16 points < 64 coefficients: "d was larger than D"
+    sh.close()
+    full.close()
