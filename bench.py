@@ -489,14 +489,14 @@ def main():
             t_dec = time.perf_counter() - t0
             result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_chain / args.asdl_steps * 1e3,
                                     "verifier_ms_each": t_ver / args.asdl_steps * 1e3, "decider_ms": t_dec * 1e3, "all_accepted": True}
-    if world > 1 and args.open_steps > 0 and world & (world - 1) == 0 and n % world == 0:
+    if (world > 1 or force_dist) and args.open_steps > 0 and world & (world - 1) == 0 and n % world == 0:
         # BASELINE configs[2] on N GPUs: pcdl::open + check with the key, the coefficients and the z-powers placed cyclically
         # (element i on rank i mod N; sharded.ShardedOpen): per round one all-gather of 256 B per rank, no vector exchange;
         # the check's commitment to h is sharded the same way (halo_pcdl_check_partial).  The same polynomial as at N = 1
         # (seed ...03); a rank's coefficients c[r::N] are handed over in host memory at every open.
         from halo_accumulation_amd.sharded import ShardedOpen, make_allgather
         ag = make_allgather(coll_dev)
-        so = ShardedOpen(h._lib, rank, world, ag, device=gpu)
+        so = ShardedOpen(h._lib, rank, world, ag, device=gpu, always_collective=force_dist)
         sctx = so.load_key(n)
         sctx.set_fold_table(1)  # the comb table of the first fold over this rank's shard, built at the first (warm-up) open
         d_co = torch.empty((n + 2) * 4, dtype=torch.int64, device=dev)
@@ -528,7 +528,9 @@ def main():
             same = want.tolist() == pi.tolist()
             pcdl.check_proof(full_o, C, n - 1, z_open, v_open, pi)
             full_o.close()
-            result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False, "ranks": world,
+            # (HALO_BENCH_FORCE_DIST=1: one rank running the collectives of the N > 1 path -- kept next to the N = 1 figure)
+            result["pcdl_open_check" if world > 1 else "pcdl_open_check_collective_path"] = {
+                                         "value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False, "ranks": world,
                                          "samples_ms": [round(x * 1e3, 3) for x in ts], "proof_equals_single_gpu": same,
                                          "note": "sharded.ShardedOpen: cyclic shards of G, c, z-powers; per round one all-gather of 256 B per "
                                                  "rank; check = succinct check on every rank + sharded commitment to h; max over ranks "

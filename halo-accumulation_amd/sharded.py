@@ -149,9 +149,10 @@ class ShardedOpen:
     allgather(arr) -> (P, len(arr)) uint64 is supplied by the caller (torch.distributed over RCCL or gloo).
     """
 
-    def __init__(self, lib, rank: int, world: int, allgather, device: int = 0):
+    def __init__(self, lib, rank: int, world: int, allgather, device: int = 0, always_collective: bool = False):
         assert world & (world - 1) == 0, "world size must be a power of two"
         self.lib, self.rank, self.world, self.allgather, self.device = lib, rank, world, allgather, device
+        self.coll = world > 1 or (always_collective and allgather is not None)  # one rank: run the collectives anyway (rehearsals)
         self.ctx = None
 
     def load_key(self, n: int, first_index: int = 2):
@@ -168,7 +169,7 @@ class ShardedOpen:
         from . import pcdl
         from ._lib import HaloReject, point_sum
         U, part = pcdl.check_partial(self.ctx, Cm, d, z, v, proof, self.world, self.rank)
-        parts = self.allgather(part) if self.world > 1 else part[None]
+        parts = self.allgather(part) if self.coll else part[None]
         comm = point_sum(parts)
         if comm.tolist() != U.tolist():  # both normalised: (x, y, 1) or (1, 1, 0)
             raise HaloReject("U != CM.Commit(ck, h_vec)")
@@ -176,7 +177,7 @@ class ShardedOpen:
     def _rounds(self, ipa, count, Hp, xi, Ls, Rs, world):
         for _ in range(count):
             rec = ipa.round_lr_partial()
-            parts = self.allgather(rec) if world > 1 else rec[None]
+            parts = self.allgather(rec) if self.coll else rec[None]
             L, R, xi, xi_inv = self.lib.open_combine(parts, Hp, xi)
             Ls.append(L)
             Rs.append(R)
@@ -195,13 +196,13 @@ class ShardedOpen:
         Cbar = wp = None
         if hiding:
             cb_part = ipa.hiding_partial(rng[0], deg, z, P, self.rank)  # slice of p_bar from the stream + its MSM
-            rec = self.allgather(np.concatenate([v_part, cb_part])) if P > 1 else np.concatenate([v_part, cb_part])[None]
+            rec = self.allgather(np.concatenate([v_part, cb_part])) if self.coll else np.concatenate([v_part, cb_part])[None]
             v_parts = np.ascontiguousarray(rec[:, :4])
             Cbar, alpha, wp, C_prime, rng[0] = self.lib.open_hiding_combine(Cm, z, v_parts, np.ascontiguousarray(rec[:, 4:]), w, rng[0], deg)
             ipa.apply_hiding(alpha)  # p' = p + alpha p_bar
             Cm = C_prime
         else:
-            v_parts = self.allgather(v_part) if P > 1 else v_part[None]
+            v_parts = self.allgather(v_part) if self.coll else v_part[None]
         v, xi, Hp = self.lib.open_start(Cm, z, v_parts)
         Ls, Rs = [], []
         xi = self._rounds(ipa, nl.bit_length() - 1, Hp, xi, Ls, Rs, P)

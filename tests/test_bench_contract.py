@@ -65,6 +65,26 @@ def test_bench_two_ranks_report_msms_and_the_sharded_open():
     assert oc["ranks"] == 2 and oc["value"] > 0 and oc["proof_equals_single_gpu"] is True and len(oc["samples_ms"]) == 2
 
 
+@pytest.mark.gpu
+def test_bench_collective_path_over_rccl_with_one_rank():
+    """The N > 1 code path with its collectives on RCCL (backend "nccl"), as far as one GPU can take it: one rank that still
+    runs every all-gather of the sharded MSM and of the sharded open + check (HALO_BENCH_FORCE_DIST=1)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HALO_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("HALO_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--steps", "6", "--warmup", "1", "--cpu-msms", "0",
+                          "--open-steps", "2", "--asdl-steps", "0", "--host-steps", "0", "--fr-reps", "0", "--min-seconds", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["config"]["collective_backend"] == "nccl" and r["value"] > 0
+    oc = r["pcdl_open_check_collective_path"]
+    assert oc["ranks"] == 1 and oc["proof_equals_single_gpu"] is True and oc["value"] > 0
+
+
 def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head, _, tail = src.partition("if args.cpu_msms > 0:")

@@ -33,6 +33,7 @@ cp(os.path.join(ev, "fr29_bench.txt"), "microbench_fr29_product.txt")
 cp(os.path.join(ev, "asdl64.json"), "asdl64_n2_20.json")
 for n in (2, 4, 8):
     cp(os.path.join(ev, "bench_oneproc%d.json" % n), "rehearsal_oneproc%d_shards_on_1gpu.json" % n)
+cp(os.path.join(ev, "bench_rccl1.json"), "rehearsal_rccl_one_rank_collective_path.json")
 for f in glob.glob(os.path.join(ev, "bench_gloo*.json")):
     cp(f, "rehearsal_%s_ranks_on_1gpu.json" % os.path.basename(f)[len("bench_"):-len(".json")])
 t = os.path.join(ev, "pytest_gpu.txt")

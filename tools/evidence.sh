@@ -35,6 +35,8 @@ python tools/pmc_summary.py $OUT/open_fetch $OUT/open_write "python3 tools/open_
 for N in 2 4 8; do
   step oneproc$N; timeout -k 10 300 python bench.py --gpus $N --one-process --devices $(python -c "print(','.join(['0']*$N))") --steps 64 --min-seconds 0.3 > $OUT/bench_oneproc$N.json 2> $OUT/bench_oneproc$N.err || exit 1
 done
+# the N > 1 path with its collectives on RCCL, as far as one GPU goes: ONE rank that still runs every all-gather
+step rccl1; HALO_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29540 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 400 python bench.py --steps 64 --warmup 8 --cpu-msms 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --min-seconds 0.3 2> $OUT/bench_rccl1.err | grep '^{' > $OUT/bench_rccl1.json || exit 1
 export HALO_BENCH_BACKEND=gloo
 for N in 2 4; do
   step gloo$N; timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 64 --warmup 8 2> $OUT/bench_gloo$N.err | grep '^{' > $OUT/bench_gloo$N.json || exit 1
