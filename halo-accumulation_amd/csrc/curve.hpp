@@ -55,6 +55,8 @@ HALO_DEV AffN aff_load(const uint32_t *p) {
     r.y.v[6] = e.x; r.y.v[7] = e.y; r.y.v[8] = e.z;
     return r;
 }
+// A native affine point owns a whole 128-byte line: x at words 0..8, y at 10..18 and -y at 20..28 (the signed-digit bucket
+// kernels pick y or -y by ADDRESS instead of negating in registers: ~45 of the ~1970 instructions of an addition)
 HALO_DEV void aff_store(uint32_t *p, const AffN &a) {
     uint4 *q = reinterpret_cast<uint4 *>(p);
     q[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
@@ -62,6 +64,27 @@ HALO_DEV void aff_store(uint32_t *p, const AffN &a) {
     q[2] = make_uint4(a.x.v[8], 0u, a.y.v[0], a.y.v[1]);
     q[3] = make_uint4(a.y.v[2], a.y.v[3], a.y.v[4], a.y.v[5]);
     q[4] = make_uint4(a.y.v[6], a.y.v[7], a.y.v[8], 0u);
+    Fq<2> ny = fq_neg<2>(a.y);
+    if (fq_limbs_zero(a.y)) ny = fq_zero<2>();  // the (0, 0) infinity marker reads (0, 0) with either sign
+    q[5] = make_uint4(ny.v[0], ny.v[1], ny.v[2], ny.v[3]);
+    q[6] = make_uint4(ny.v[4], ny.v[5], ny.v[6], ny.v[7]);
+    q[7] = make_uint4(ny.v[8], 0u, 0u, 0u);
+}
+// (x, y) or (x, -y): the sign picks which stored copy of y is read (both 8-byte aligned: words 10.. and 20..)
+HALO_DEV AffN aff_load_signed(const uint32_t *p, bool negate) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    uint32_t x8 = p[8];
+    const uint2 *py = reinterpret_cast<const uint2 *>(p + (negate ? 20 : 10));
+    uint2 y0 = py[0], y1 = py[1], y2 = py[2], y3 = py[3];
+    uint32_t y8 = reinterpret_cast<const uint32_t *>(py)[8];
+    AffN r;
+    r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+    r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+    r.x.v[8] = x8;
+    r.y.v[0] = y0.x; r.y.v[1] = y0.y; r.y.v[2] = y1.x; r.y.v[3] = y1.y; r.y.v[4] = y2.x; r.y.v[5] = y2.y;
+    r.y.v[6] = y3.x; r.y.v[7] = y3.y; r.y.v[8] = y8;
+    return r;
 }
 // arkworks affine words (x | y, 8 u64, (0,0) = infinity) <-> native
 HALO_DEV AffN aff_from_words(const uint64_t *w) {

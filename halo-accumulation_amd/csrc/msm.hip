@@ -1001,11 +1001,12 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t *__restri
     uint32_t e = rec.w;
     uint32_t last = cnt - 1;
     uint32_t e1 = sorted[st + (1 < last ? 1 : last)];
-    AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+    // (the sign of the digit picks the stored y or -y of the entry by address: aff_load_signed)
+    AffN nxt = aff_load_signed(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu), (e >> 31) != 0);
     for (uint32_t k = 0; k < cnt; k++) {
-        AffN p = aff_cneg(nxt, (e >> 31) != 0);
+        AffN p = nxt;
         e = e1;
-        if (k + 1 < cnt) nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+        if (k + 1 < cnt) nxt = aff_load_signed(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu), (e >> 31) != 0);
         e1 = sorted[st + (k + 2 < last ? k + 2 : last)];
         xyzz_madd(acc, p);
     }

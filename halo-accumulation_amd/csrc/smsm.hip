@@ -274,11 +274,11 @@ __global__ __launch_bounds__(256) void k_smsm_accumulate(const uint32_t *__restr
         uint32_t e = sorted[st];
         uint32_t last = cnt - 1;
         uint32_t e1 = sorted[st + (1 < last ? 1 : last)];
-        AffN nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+        AffN nxt = aff_load_signed(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu), (e >> 31) != 0);
         for (uint32_t k = 0; k < cnt; k++) {
-            AffN p = aff_cneg(nxt, (e >> 31) != 0);
+            AffN p = nxt;
             e = e1;
-            if (k + 1 < cnt) nxt = aff_load(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu));
+            if (k + 1 < cnt) nxt = aff_load_signed(bases + AFF_STRIDE * (size_t)(e & 0x7fffffffu), (e >> 31) != 0);
             e1 = sorted[st + (k + 2 < last ? k + 2 : last)];
             xyzz_madd(acc, p);
         }
