@@ -72,6 +72,7 @@ struct MsmPlan {
     int table_vw_bits = 15;  // log2 of the buckets per virtual window
     int table_pieces = 1;    // a large table MSM runs as this many consecutive pieces: 2 * table_sets * table_vw sums each
     int table_sets = 1;      // bucket sets side by side in a batched table launch (members, rounded up to a power of two)
+    bool table_rc = false;   // window sums by rows and columns of the bucket index (msm.hip k_msm_reduce_rc): 24 (S, T) pairs per piece
 };
 constexpr int MSM_MAX_BATCH = 8;
 // fixed-base table plan of a context (msm.hip: table_plan)
@@ -334,7 +335,9 @@ int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, 
 int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
-int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain);
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain,
+                       const uint32_t *seg = nullptr);
+int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum);
 int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
                  uint32_t kmax);
 int smsm_prepare();

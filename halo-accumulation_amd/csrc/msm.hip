@@ -1131,6 +1131,46 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
 }
 // The segments of a window are combined by k_smsm_final (smsm.hip, quad-parallel): see quad_final_enqueue.
 
+// Window sums of ONE set of 2^19 buckets (the c = 20 table plan) by rows and columns of the bucket index b = hi 2^10 + lo:
+//     sum_b (b + 1) B_b  =  sum_lo (lo + 1) C_lo  +  2^10 sum_hi hi R_hi,     C_lo = sum_hi B_(hi,lo),  R_hi = sum_lo B_(hi,lo)
+// C and R are PLAIN sums: every lane adds 16 buckets and a shuffle tree finishes the row (64 lanes) or the two columns
+// (32 lanes each) of its wave -- 22 dependent additions where the running-sum form (k_msm_reduce1: 16 in the lane, then a
+// wave-wide weighted sum of 16 more) takes 32, for the same 1024 waves.  The weights come afterwards, over 1024 + 512 points
+// instead of 2^19 (k_rc_mid + k_smsm_final, quad-parallel).  Blocks [0, 512): columns 2 blk, 2 blk + 1; [512, 1024): row blk - 512.
+// ent: columns at [0, 1024), rows at [1024, 1536).
+constexpr uint32_t RC_LO_BITS = 10, RC_ROWS = 512, RC_COLS = 1024;
+constexpr uint32_t RC_POINTS = 2 * (RC_ROWS + RC_COLS) / 64;  // (S, T) per block of 64 entries: 48 window-sum slots per piece
+__global__ __launch_bounds__(64) void k_msm_reduce_rc(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
+                                                      const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
+                                                      uint32_t *__restrict__ ent) {
+    const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+    const bool row = blk >= RC_COLS / 2;
+    uint32_t g0, stride, width, slot;
+    if (row) {
+        uint32_t hi = blk - RC_COLS / 2;
+        g0 = (hi << RC_LO_BITS) + lane; stride = 64; width = 64; slot = RC_COLS + hi;  // lo = lane + 64 i: coalesced
+    } else {
+        uint32_t col = 2 * blk + (lane >> 5), t = lane & 31;
+        g0 = (t << RC_LO_BITS) + col; stride = 32u << RC_LO_BITS; width = 32; slot = col;  // hi = t + 32 i
+    }
+    XyzzN acc = xyzz_inf();
+    XyzzN b = bucket_value(partial, ntask, toff, tblockoff, g0);
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16; i++) {
+        XyzzN nb = xyzz_inf();
+        if (i + 1 < 16) nb = bucket_value(partial, ntask, toff, tblockoff, g0 + (i + 1) * stride);  // in flight during the addition
+        xyzz_add(acc, b);
+        b = nb;
+    }
+    const uint32_t sub = lane & (width - 1);
+#pragma unroll 1
+    for (uint32_t off = width >> 1; off >= 1; off >>= 1) {
+        XyzzN o = xyzz_shfl(acc, (int)((lane + off) & 63));
+        if (sub < off) xyzz_add(acc, o);
+    }
+    if (sub == 0) xyzz_store(ent + XYZZ_WORDS * (size_t)slot, acc);
+}
+
 // ------------------------------------------------------------------------------ K10 / K11 / format conversion
 // arkworks Jacobian words -> native affine: TBL_E points per lane, one shared Fermat inversion (jac_batch_to_aff)
 __global__ __launch_bounds__(256) void k_batch_to_affine(const uint64_t *__restrict__ jac, uint32_t n, uint32_t *__restrict__ out) {
@@ -1520,7 +1560,7 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     need.windows = 64;
     {   // the table pipeline runs a large MSM in pieces and keeps 2 x 16 window sums per piece
         size_t pieces = (n + TBL_PIECE - 1) / TBL_PIECE;
-        if (32 * pieces > need.windows) need.windows = 32 * pieces;
+        if (RC_POINTS * pieces > need.windows) need.windows = RC_POINTS * pieces;  // (or 24 (S, T) pairs: k_msm_reduce_rc)
     }
     alloc_epoch_bump(ctx);
     return workspace_alloc(ctx->wss[slot], need);
@@ -1746,6 +1786,11 @@ static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const M
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
 static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece);
+// the row / column window sums (k_msm_reduce_rc) serve the one-member launch of the c = 20 plan: one set of 2^19 buckets
+static bool table_rc_plan(const TblPlan &tp, uint32_t sets) {
+    static const bool off = getenv("HALO_REDUCE_RC") && atoi(getenv("HALO_REDUCE_RC")) == 0;  // development switch: the older form
+    return !off && tp.c == 20 && sets == 1 && tp.B == (RC_ROWS << RC_LO_BITS);
+}
 // A batch is about throughput: its window sums take 2^15-bucket virtual windows (8 buckets per lane) like the large plan --
 // with 2^12 (one bucket per lane: the short chain a single MSM wants) the wave-wide step of k_msm_reduce1 cost as many
 // instructions as the bucket kernel itself.
@@ -1759,7 +1804,10 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
     uint32_t cpow = 1;  // a batch (small-key plan, one piece) lays its members' bucket sets side by side: a power of two of them
     while ((int)cpow < members.count) cpow <<= 1;
-    if (2 * tp.vw * pieces * cpow > ws.cap_windows) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
+    if (2 * tp.vw * pieces * cpow > ws.cap_windows || (table_rc_plan(tp, cpow) && RC_POINTS * pieces > ws.cap_windows)) {
+        set_error("msm: table plan exceeds workspace");
+        return HALO_E_ARG;
+    }
     size_t len = ((n + pieces - 1) / pieces + 3) / 4 * 4, off = 0;
     for (size_t k = 0; k < pieces; ++k, off += len) {
         size_t m = off + len <= n ? len : n - off;  // (n and len are multiples of 4)
@@ -1770,6 +1818,7 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = members.count; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
     p.table_pieces = (int)pieces;
     p.table_sets = (int)cpow;
+    p.table_rc = table_rc_plan(tp, cpow);
     ws.plan = p;
     return HALO_OK;
 }
@@ -1823,6 +1872,18 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 total, 512u, ws.d_buckets);
     // window sums: the buckets as tp.vw virtual windows of 2^vw_bits, 64 segments each (c = 20: 8 buckets per lane; c = 17: 1)
+    if (table_rc_plan(tp, cpow)) {
+        // rows and columns of the bucket index (k_msm_reduce_rc): 1024 + 512 entries, then 24 blocks of 64 entries -> 24 (S, T)
+        // pairs per piece, combined on the host
+        uint64_t *d_rc = ws.d_winsum + (size_t)piece * RC_POINTS * 12;
+        HALO_LAUNCH(ctx, "k_msm_reduce_rc", k_msm_reduce_rc, dim3(RC_COLS / 2 + RC_ROWS), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_seg);
+        int rc = rc_mid_enqueue(ctx, ws.d_seg, RC_POINTS / 2, d_rc);
+        if (rc) return rc;
+        HALO_HIP(hipGetLastError());
+        HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * RC_POINTS * 12, d_rc, (size_t)RC_POINTS * 96, hipMemcpyDeviceToHost, s));
+        return HALO_OK;
+    }
+    uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
     uint32_t vwB = 1u << tp.vw_bits;
     uint32_t L = vwB / 4096 ? vwB / 4096 : 1, nseg = vwB / (64 * L);
     if (tp.vw_bits == 15 && (ctx->reduce_span == 16 || ctx->reduce_span == 32 || ctx->reduce_span == 64)) { L = (uint32_t)ctx->reduce_span; nseg = 512 / L; }
@@ -1830,7 +1891,6 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     while ((1u << logL) < L) logL++;
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(tp.vw * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, vwB, L, logL,
                 nseg, ws.d_seg);
-    uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
     {
         int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, d_out, d_out + 12 * tp.vw);
         if (rc) return rc;
@@ -1983,6 +2043,33 @@ void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out) {
     MsmPlan p = ws.plan;
     *out = host::Point::infinity();
     if (p.W == 0) return;
+    if (p.table_vw > 0 && p.table_rc) {
+        // per piece 24 pairs (S_q, T_q) = (sum E, sum (Q + 1) E) over 64 entries each: 16 of columns, then 8 of rows.
+        //   sum_lo (lo + 1) C_lo = sum_q T_q + 64 sum_q q S_q     (q < 16);   sum_hi (hi + 1) R_hi likewise (q < 8)
+        //   sum_b (b + 1) B_b = [columns] + 2^10 ([rows] - sum_hi R_hi)
+        auto weighted = [&](int first, int count, host::Point *plain) {
+            host::Point t = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
+            for (int q = count - 1; q >= 0; --q) {
+                host::Point sq = host::Point::infinity();
+                for (int k = 0; k < p.table_pieces; ++k) {
+                    const uint64_t *w = ws.h_winsum + 12 * ((size_t)k * RC_POINTS + 2 * (size_t)(first + q));
+                    sq = sq + host::Point::load(w);
+                    t = t + host::Point::load(w + 12);
+                }
+                if (q >= 1) { run = run + sq; tot = tot + run; }  // tot = sum_q q S_q by running sums
+                else run = run + sq;
+            }
+            for (int k = 0; k < 6 && !tot.is_inf(); ++k) tot = tot.dbl();
+            if (plain) *plain = run;
+            return t + tot;
+        };
+        host::Point s_rows;
+        host::Point cols = weighted(0, (int)(RC_COLS / 64), nullptr);
+        host::Point rows = weighted((int)(RC_COLS / 64), (int)(RC_ROWS / 64), &s_rows) - s_rows;
+        for (uint32_t k = 0; k < RC_LO_BITS && !rows.is_inf(); ++k) rows = rows.dbl();
+        *out = cols + rows;
+        return;
+    }
     if (p.table_vw > 0) {
         // virtual window v holds the buckets v 2^b + 1 .. (v + 1) 2^b (b = table_vw_bits): sum_v [ T_v + v 2^b S_v ];
         // a piece (large MSM) or a batch stores sets * V weighted sums, then sets * V plain sums; member b owns set b

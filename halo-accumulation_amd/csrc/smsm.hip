@@ -542,10 +542,33 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
 // The last step of the sorted pipelines of msm.hip as well: the (S, T) records k_msm_reduce1 left per segment (nseg <= 64
 // per window, 2^k buckets each) -> window sums.  A chain of ~20 dependent point operations run by Wt blocks: the quad
 // form takes 80 us where one wave per window took 130.
-int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain) {
+int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain,
+                       const uint32_t *seg) {
     int live_seg = 1;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
-    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, k, live_seg, winsum, winsum_plain);
+    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, seg ? seg : ws.d_seg, nseg, k, live_seg, winsum, winsum_plain);
+    return HALO_OK;
+}
+
+// Last device step of the row / column window sums (msm.hip k_msm_reduce_rc): block w takes 64 consecutive entries E_0..E_63
+// (single points) and leaves (S, T) = (sum E_Q, sum (Q + 1) E_Q) as Jacobian words at winsum[2 w], winsum[2 w + 1]: the same
+// quad-parallel weighted sum as k_smsm_final, fed with S = T = E.  The 24 pairs are combined on the host (msm_combine_member:
+// ~70 additions; a second launch for them was 66 us of latency chain).
+__global__ __launch_bounds__(256, 2) void k_rc_mid(const uint32_t *__restrict__ ent, uint64_t *__restrict__ winsum) {
+    __shared__ uint32_t xch[64 * XYZZ_WORDS], parkS[64 * XYZZ_WORDS], parkT[64 * XYZZ_WORDS];
+    uint32_t w = blockIdx.x;
+    int tid = threadIdx.x, ql = tid & 3, Q = tid >> 2;
+    XyzzN S = xyzz_load(ent + XYZZ_WORDS * ((size_t)w * 64 + (uint32_t)Q));
+    XyzzN T = S;
+    park_put(parkT, Q, ql, T);
+    block_weighted_sum(S, T, 0, xch, parkS, parkT, Q, ql, 64);
+    if (tid == 0) {
+        xyzz_store_jac_words(winsum + 24 * (size_t)w, S);
+        xyzz_store_jac_words(winsum + 24 * (size_t)w + 12, T);
+    }
+}
+int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum) {
+    HALO_LAUNCH(ctx, "k_rc_mid", k_rc_mid, dim3(blocks), dim3(256), 0, entries, winsum);
     return HALO_OK;
 }
 
