@@ -72,7 +72,8 @@ struct MsmPlan {
     int table_vw_bits = 15;  // log2 of the buckets per virtual window
     int table_pieces = 1;    // a large table MSM runs as this many consecutive pieces: 2 * table_sets * table_vw sums each
     int table_sets = 1;      // bucket sets side by side in a batched table launch (members, rounded up to a power of two)
-    bool table_rc = false;   // window sums by rows and columns of the bucket index (msm.hip k_msm_reduce_rc): 24 (S, T) pairs per piece
+    bool table_rc = false;   // window sums by rows and columns of the bucket index (msm.hip k_msm_reduce_rc): (S, T) pairs per set
+    int table_rc_lg_rows = 0, table_rc_lg_cols = 0;
 };
 constexpr int MSM_MAX_BATCH = 8;
 // fixed-base table plan of a context (msm.hip: table_plan)

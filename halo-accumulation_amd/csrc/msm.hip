@@ -1133,34 +1133,45 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
 
 // Window sums of ONE set of 2^19 buckets (the c = 20 table plan) by rows and columns of the bucket index b = hi 2^10 + lo:
 //     sum_b (b + 1) B_b  =  sum_lo (lo + 1) C_lo  +  2^10 sum_hi hi R_hi,     C_lo = sum_hi B_(hi,lo),  R_hi = sum_lo B_(hi,lo)
-// C and R are PLAIN sums: every lane adds 16 buckets and a shuffle tree finishes the row (64 lanes) or the two columns
-// (32 lanes each) of its wave -- 22 dependent additions where the running-sum form (k_msm_reduce1: 16 in the lane, then a
-// wave-wide weighted sum of 16 more) takes 32, for the same 1024 waves.  The weights come afterwards, over 1024 + 512 points
-// instead of 2^19 (k_rc_mid + k_smsm_final, quad-parallel).  Blocks [0, 512): columns 2 blk, 2 blk + 1; [512, 1024): row blk - 512.
-// ent: columns at [0, 1024), rows at [1024, 1536).
-constexpr uint32_t RC_LO_BITS = 10, RC_ROWS = 512, RC_COLS = 1024;
-constexpr uint32_t RC_POINTS = 2 * (RC_ROWS + RC_COLS) / 64;  // (S, T) per block of 64 entries: 48 window-sum slots per piece
+// C and R are PLAIN sums: every lane adds `per` buckets and a shuffle tree finishes the rows or columns of its wave -- for the
+// c = 20 plan 16 + 6 dependent additions where the running-sum form (k_msm_reduce1: 16 in the lane, then a wave-wide weighted
+// sum of 16 more) takes 32, for the same 1024 waves.  The weights come afterwards, over rows + columns points instead of all
+// buckets (k_rc_mid, quad-parallel, then ~70 additions on the host).
+//   shape            buckets per set      rows x columns   per lane   lanes per row / column
+//   c = 20, 1 set         2^19              512 x 1024        16            64 / 32
+//   c = 17, 8 sets        2^16              256 x 256         16            16 / 16      (batches of the small-key plan:
+//   c = 17, 4 sets        2^16              256 x 256          8            32 / 32       the chip's 65536 lanes read
+//   c = 17, 2 sets        2^16              256 x 256          4            64 / 64       every bucket twice)
+// Per set: blocks [0, nb) take columns, [nb, 2 nb) rows, nb = buckets / (64 per).  ent (per set): columns, then rows.
+struct RcShape { int lg_rows = 0, lg_cols = 0, per = 0; };
+static inline uint32_t rc_points(const RcShape &r) { return r.per ? 2u * ((1u << r.lg_rows) + (1u << r.lg_cols)) / 64u : 0u; }  // (S, T) pairs x 2, per set
 __global__ __launch_bounds__(64) void k_msm_reduce_rc(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ ntask,
                                                       const uint32_t *__restrict__ toff, const uint32_t *__restrict__ tblockoff,
-                                                      uint32_t *__restrict__ ent) {
-    const uint32_t lane = threadIdx.x, blk = blockIdx.x;
-    const bool row = blk >= RC_COLS / 2;
+                                                      RcShape sh, uint32_t *__restrict__ ent) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t rows = 1u << sh.lg_rows, cols = 1u << sh.lg_cols, per = (uint32_t)sh.per;
+    const uint32_t nb = (rows << sh.lg_cols) / (64 * per);
+    const uint32_t set = blockIdx.x / (2 * nb), r = blockIdx.x % (2 * nb);
+    const bool row = r >= nb;
     uint32_t g0, stride, width, slot;
     if (row) {
-        uint32_t hi = blk - RC_COLS / 2;
-        g0 = (hi << RC_LO_BITS) + lane; stride = 64; width = 64; slot = RC_COLS + hi;  // lo = lane + 64 i: coalesced
+        width = cols / per;                                   // lanes per row: lo = sub + width i (coalesced)
+        uint32_t hi = (r - nb) * (64 / width) + lane / width;
+        g0 = (hi << sh.lg_cols) + (lane & (width - 1)); stride = width; slot = cols + hi;
     } else {
-        uint32_t col = 2 * blk + (lane >> 5), t = lane & 31;
-        g0 = (t << RC_LO_BITS) + col; stride = 32u << RC_LO_BITS; width = 32; slot = col;  // hi = t + 32 i
+        width = rows / per;                                   // lanes per column: hi = sub + width i
+        uint32_t col = r * (64 / width) + lane / width;
+        g0 = ((lane & (width - 1)) << sh.lg_cols) + col; stride = width << sh.lg_cols; slot = col;
     }
+    g0 += set * (rows << sh.lg_cols);
     XyzzN acc = xyzz_inf();
     XyzzN b = bucket_value(partial, ntask, toff, tblockoff, g0);
 #pragma unroll 1
-    for (uint32_t i = 0; i < 16; i++) {
-        XyzzN nb = xyzz_inf();
-        if (i + 1 < 16) nb = bucket_value(partial, ntask, toff, tblockoff, g0 + (i + 1) * stride);  // in flight during the addition
+    for (uint32_t i = 0; i < per; i++) {
+        XyzzN nb2 = xyzz_inf();
+        if (i + 1 < per) nb2 = bucket_value(partial, ntask, toff, tblockoff, g0 + (i + 1) * stride);  // in flight during the addition
         xyzz_add(acc, b);
-        b = nb;
+        b = nb2;
     }
     const uint32_t sub = lane & (width - 1);
 #pragma unroll 1
@@ -1168,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce_rc(const uint32_t *__restrict
         XyzzN o = xyzz_shfl(acc, (int)((lane + off) & 63));
         if (sub < off) xyzz_add(acc, o);
     }
-    if (sub == 0) xyzz_store(ent + XYZZ_WORDS * (size_t)slot, acc);
+    if (sub == 0) xyzz_store(ent + XYZZ_WORDS * ((size_t)set * (rows + cols) + slot), acc);
 }
 
 // ------------------------------------------------------------------------------ K10 / K11 / format conversion
@@ -1560,7 +1571,8 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     need.windows = 64;
     {   // the table pipeline runs a large MSM in pieces and keeps 2 x 16 window sums per piece
         size_t pieces = (n + TBL_PIECE - 1) / TBL_PIECE;
-        if (RC_POINTS * pieces > need.windows) need.windows = RC_POINTS * pieces;  // (or 24 (S, T) pairs: k_msm_reduce_rc)
+        if (48 * pieces > need.windows) need.windows = 48 * pieces;  // (or 24 (S, T) pairs per piece: k_msm_reduce_rc)
+        if (need.windows < 128) need.windows = 128;                  // (a batch of 8 of the small-key plan: 8 x 8 pairs)
     }
     alloc_epoch_bump(ctx);
     return workspace_alloc(ctx->wss[slot], need);
@@ -1786,10 +1798,14 @@ static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const M
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
 static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece);
-// the row / column window sums (k_msm_reduce_rc) serve the one-member launch of the c = 20 plan: one set of 2^19 buckets
-static bool table_rc_plan(const TblPlan &tp, uint32_t sets) {
+// the shape of the row / column window sums (k_msm_reduce_rc) for a launch of `sets` bucket sets of B buckets each; per = 0: none
+static RcShape table_rc_shape(int c, uint32_t B, uint32_t sets) {
     static const bool off = getenv("HALO_REDUCE_RC") && atoi(getenv("HALO_REDUCE_RC")) == 0;  // development switch: the older form
-    return !off && tp.c == 20 && sets == 1 && tp.B == (RC_ROWS << RC_LO_BITS);
+    RcShape r;
+    if (off) return r;
+    if (c == 20 && sets == 1 && B == (1u << 19)) { r.lg_rows = 9; r.lg_cols = 10; r.per = 16; }
+    else if (c == 17 && B == (1u << 16) && (sets == 2 || sets == 4 || sets == 8)) { r.lg_rows = 8; r.lg_cols = 8; r.per = (int)(2 * sets); }
+    return r;
 }
 // A batch is about throughput: its window sums take 2^15-bucket virtual windows (8 buckets per lane) like the large plan --
 // with 2^12 (one bucket per lane: the short chain a single MSM wants) the wave-wide step of k_msm_reduce1 cost as many
@@ -1804,7 +1820,8 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
     uint32_t cpow = 1;  // a batch (small-key plan, one piece) lays its members' bucket sets side by side: a power of two of them
     while ((int)cpow < members.count) cpow <<= 1;
-    if (2 * tp.vw * pieces * cpow > ws.cap_windows || (table_rc_plan(tp, cpow) && RC_POINTS * pieces > ws.cap_windows)) {
+    const RcShape rcs = table_rc_shape(tp.c, tp.B, cpow);
+    if (2 * tp.vw * pieces * cpow > ws.cap_windows || rc_points(rcs) * cpow * pieces > ws.cap_windows) {
         set_error("msm: table plan exceeds workspace");
         return HALO_E_ARG;
     }
@@ -1818,7 +1835,9 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = members.count; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
     p.table_pieces = (int)pieces;
     p.table_sets = (int)cpow;
-    p.table_rc = table_rc_plan(tp, cpow);
+    p.table_rc = rcs.per != 0;
+    p.table_rc_lg_rows = rcs.lg_rows;
+    p.table_rc_lg_cols = rcs.lg_cols;
     ws.plan = p;
     return HALO_OK;
 }
@@ -1872,15 +1891,17 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     HALO_LAUNCH(ctx, "k_msm_combine", k_msm_combine, dim3(512 + 1024), dim3(64), 0, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_meta, ws.d_biglist,
                 total, 512u, ws.d_buckets);
     // window sums: the buckets as tp.vw virtual windows of 2^vw_bits, 64 segments each (c = 20: 8 buckets per lane; c = 17: 1)
-    if (table_rc_plan(tp, cpow)) {
-        // rows and columns of the bucket index (k_msm_reduce_rc): 1024 + 512 entries, then 24 blocks of 64 entries -> 24 (S, T)
-        // pairs per piece, combined on the host
-        uint64_t *d_rc = ws.d_winsum + (size_t)piece * RC_POINTS * 12;
-        HALO_LAUNCH(ctx, "k_msm_reduce_rc", k_msm_reduce_rc, dim3(RC_COLS / 2 + RC_ROWS), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, ws.d_seg);
-        int rc = rc_mid_enqueue(ctx, ws.d_seg, RC_POINTS / 2, d_rc);
+    const RcShape rcs = table_rc_shape(tp.c, tp.B / cpow, cpow);
+    if (rcs.per) {
+        // rows and columns of the bucket index (k_msm_reduce_rc): rows + columns entries per set, then blocks of 64 entries ->
+        // (S, T) pairs, combined on the host (msm_combine_member)
+        const uint32_t pts = rc_points(rcs) * cpow, nb = (tp.B / cpow) / (64u * (uint32_t)rcs.per);
+        uint64_t *d_rc = ws.d_winsum + (size_t)piece * pts * 12;
+        HALO_LAUNCH(ctx, "k_msm_reduce_rc", k_msm_reduce_rc, dim3(cpow * 2 * nb), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, rcs, ws.d_seg);
+        int rc = rc_mid_enqueue(ctx, ws.d_seg, pts / 2, d_rc);
         if (rc) return rc;
         HALO_HIP(hipGetLastError());
-        HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * RC_POINTS * 12, d_rc, (size_t)RC_POINTS * 96, hipMemcpyDeviceToHost, s));
+        HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * pts * 12, d_rc, (size_t)pts * 96, hipMemcpyDeviceToHost, s));
         return HALO_OK;
     }
     uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
@@ -2044,29 +2065,31 @@ void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out) {
     *out = host::Point::infinity();
     if (p.W == 0) return;
     if (p.table_vw > 0 && p.table_rc) {
-        // per piece 24 pairs (S_q, T_q) = (sum E, sum (Q + 1) E) over 64 entries each: 16 of columns, then 8 of rows.
-        //   sum_lo (lo + 1) C_lo = sum_q T_q + 64 sum_q q S_q     (q < 16);   sum_hi (hi + 1) R_hi likewise (q < 8)
-        //   sum_b (b + 1) B_b = [columns] + 2^10 ([rows] - sum_hi R_hi)
+        // per piece and set: pairs (S_q, T_q) = (sum E, sum (Q + 1) E) over 64 entries each, the columns' first, then the rows'.
+        //   sum_lo (lo + 1) C_lo = sum_q T_q + 64 sum_q q S_q;   sum_hi (hi + 1) R_hi likewise
+        //   sum_b (b + 1) B_b = [columns] + 2^lg_cols ([rows] - sum_hi R_hi)
+        const int cblocks = (1 << p.table_rc_lg_cols) / 64, rblocks = (1 << p.table_rc_lg_rows) / 64;
+        const size_t set_pts = 2 * (size_t)(cblocks + rblocks), piece_pts = set_pts * (size_t)p.table_sets;
         auto weighted = [&](int first, int count, host::Point *plain) {
             host::Point t = host::Point::infinity(), run = host::Point::infinity(), tot = host::Point::infinity();
             for (int q = count - 1; q >= 0; --q) {
                 host::Point sq = host::Point::infinity();
                 for (int k = 0; k < p.table_pieces; ++k) {
-                    const uint64_t *w = ws.h_winsum + 12 * ((size_t)k * RC_POINTS + 2 * (size_t)(first + q));
+                    const uint64_t *w = ws.h_winsum + 12 * ((size_t)k * piece_pts + (size_t)b * set_pts + 2 * (size_t)(first + q));
                     sq = sq + host::Point::load(w);
                     t = t + host::Point::load(w + 12);
                 }
-                if (q >= 1) { run = run + sq; tot = tot + run; }  // tot = sum_q q S_q by running sums
-                else run = run + sq;
+                run = run + sq;
+                if (q >= 1) tot = tot + run;  // tot = sum_q q S_q by running sums
             }
             for (int k = 0; k < 6 && !tot.is_inf(); ++k) tot = tot.dbl();
             if (plain) *plain = run;
             return t + tot;
         };
         host::Point s_rows;
-        host::Point cols = weighted(0, (int)(RC_COLS / 64), nullptr);
-        host::Point rows = weighted((int)(RC_COLS / 64), (int)(RC_ROWS / 64), &s_rows) - s_rows;
-        for (uint32_t k = 0; k < RC_LO_BITS && !rows.is_inf(); ++k) rows = rows.dbl();
+        host::Point cols = weighted(0, cblocks, nullptr);
+        host::Point rows = weighted(cblocks, rblocks, &s_rows) - s_rows;
+        for (int k = 0; k < p.table_rc_lg_cols && !rows.is_inf(); ++k) rows = rows.dbl();
         *out = cols + rows;
         return;
     }
