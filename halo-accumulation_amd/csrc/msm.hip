@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(64) void k_msm_reduce1(const uint32_t *__restrict__
 //   c = 17, 8 sets        2^16              256 x 256         16            16 / 16      (batches of the small-key plan:
 //   c = 17, 4 sets        2^16              256 x 256          8            32 / 32       the chip's 65536 lanes read
 //   c = 17, 2 sets        2^16              256 x 256          4            64 / 64       every bucket twice)
+//   c = 17, 1 set         2^16              256 x 256          4            64 / 64      (512 waves: 4 + 6 additions deep)
 // Per set: blocks [0, nb) take columns, [nb, 2 nb) rows, nb = buckets / (64 per).  ent (per set): columns, then rows.
 struct RcShape { int lg_rows = 0, lg_cols = 0, per = 0; };
 static inline uint32_t rc_points(const RcShape &r) { return r.per ? 2u * ((1u << r.lg_rows) + (1u << r.lg_cols)) / 64u : 0u; }  // (S, T) pairs x 2, per set
@@ -1804,7 +1805,7 @@ static RcShape table_rc_shape(int c, uint32_t B, uint32_t sets) {
     RcShape r;
     if (off) return r;
     if (c == 20 && sets == 1 && B == (1u << 19)) { r.lg_rows = 9; r.lg_cols = 10; r.per = 16; }
-    else if (c == 17 && B == (1u << 16) && (sets == 2 || sets == 4 || sets == 8)) { r.lg_rows = 8; r.lg_cols = 8; r.per = (int)(2 * sets); }
+    else if (c == 17 && B == (1u << 16) && (sets == 1 || sets == 2 || sets == 4 || sets == 8)) { r.lg_rows = 8; r.lg_cols = 8; r.per = sets == 1 ? 4 : (int)(2 * sets); }
     return r;
 }
 // A batch is about throughput: its window sums take 2^15-bucket virtual windows (8 buckets per lane) like the large plan --
