@@ -1049,16 +1049,22 @@ int halo_open_tail(const uint64_t *recs, size_t P, const uint64_t Hp[12], const 
     host::Fr xi = host::Fr::load(xi_prev);
     size_t round = 0;
     for (size_t m = P / 2; m >= 1; m /= 2, ++round) {
-        host::Point L = host::Point::infinity(), R = host::Point::infinity();
         host::Fr dl = host::Fr::zero(), dr = host::Fr::zero();
         for (size_t j = 0; j < m; ++j) {
-            L = L + G[j].mul(c[m + j]);      // <c_r, G_l>   (:204)
-            R = R + G[m + j].mul(c[j]);      // <c_l, G_r>   (:208)
             dl = dl + c[m + j] * z[j];       // <c_r, z_l>   (:203)
             dr = dr + c[j] * z[m + j];       // <c_l, z_r>   (:207)
         }
-        L = (L + H.mul(dl)).normalized();
-        R = (R + H.mul(dr)).normalized();
+        // the 2 m + 2 scalar multiples of the round (~80 us each) on the host pool; summed in index order
+        std::vector<host::Point> term(2 * m + 2);
+        pool_run(2 * m + 2, [&](size_t t) {
+            if (t < m) term[t] = G[t].mul(c[m + t]);                    // <c_r, G_l>   (:204)
+            else if (t < 2 * m) term[t] = G[t].mul(c[t - m]);           // <c_l, G_r>   (:208)
+            else term[t] = H.mul(t == 2 * m ? dl : dr);
+        });
+        host::Point L = host::Point::infinity(), R = host::Point::infinity();
+        for (size_t j = 0; j < m; ++j) { L = L + term[j]; R = R + term[m + j]; }
+        L = (L + term[2 * m]).normalized();
+        R = (R + term[2 * m + 1]).normalized();
         host::Transcript t;
         t.scalar(xi); t.point(L); t.point(R);
         host::Fr x = t.finish(0);  // :212
@@ -1066,11 +1072,11 @@ int halo_open_tail(const uint64_t *recs, size_t P, const uint64_t Hp[12], const 
         host::Fr xinv = x.inv();
         L.store(Ls + 12 * round);
         R.store(Rs + 12 * round);
-        for (size_t j = 0; j < m; ++j) {
+        pool_run(m, [&](size_t j) {
             G[j] = G[j] + G[m + j].mul(x);   // :218
             c[j] = c[j] + xinv * c[m + j];   // :222
             z[j] = z[j] + x * z[m + j];      // :223
-        }
+        });
         xi = x;
     }
     G[0].store_normalized(U);  // :230

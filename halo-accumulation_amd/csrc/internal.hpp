@@ -312,6 +312,19 @@ int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
 // bases: native affine table (20 words per point)
 int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n, host::Point *out);
+// fn(0) .. fn(m - 1) on a bounded pool of host threads (at most 16; the caller's thread takes part)
+inline void pool_run(size_t m, const std::function<void(size_t)> &fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = hw ? hw : 4;
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads > m) nthreads = m;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < m;) fn(i); };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nthreads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
 int urs_generate(halo_ctx *ctx, uint64_t first_index, uint64_t stride, size_t n, uint32_t *d_out_native);
 int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac_words, size_t n, uint32_t *d_out_native);
 int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t *d_out);

@@ -274,18 +274,6 @@ static int succinct_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr
 //     C'_i + sum_j (xi_j^-1 L_j + xi_j R_j) + (v_i - c_i h_i(z_i)) xi_0 H - c_i U_i  ==  0        (pcdl.rs:288-310)
 // as 2 lg n + 2 scalar multiples per instance, compared with -C'_i on the host.  Per-instance outcome equals the host path's.
 constexpr size_t kBatchVerifyMin = 64;  // below this the host pool is faster than a 256-step device ladder (~2 ms)
-static void pool_run(size_t m, const std::function<void(size_t)> &fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nthreads = hw ? hw : 4;
-    if (nthreads > 16) nthreads = 16;
-    if (nthreads > m) nthreads = m;
-    std::atomic<size_t> next{0};
-    auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < m;) fn(i); };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nthreads; ++t) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
-}
 static int verify_staging(halo_ctx *ctx, size_t words) {
     if (words <= ctx->verify_words) return HALO_OK;
     alloc_epoch_bump(ctx);
