@@ -693,16 +693,21 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[2], st->ev, 0));
-    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream, issued BEFORE the MSMs' launches: queued
-    // behind them the two small kernels waited for the bucket kernel's waves to drain, and the H' terms, which need only
-    // the dot products, were computed after the MSMs instead of under them
-    {
+    // dot_l = <c_r, z_l>, dot_r = <c_l, z_r>   (pcdl.rs:203,207) on a third stream.  In the rounds with large MSMs they are
+    // issued BEFORE the MSMs' launches: queued behind them the two small kernels waited for the bucket kernel's waves to
+    // drain, and the H' terms, which need only the dot products, were computed after the MSMs instead of under them.  In
+    // the late rounds (an MSM of a few 10^4 additions: the GPU is mostly idle) the MSM's launches go first instead: the
+    // three API calls of the dot products would only delay its start.
+    static const int dots_env = getenv("HALO_DOTS_FIRST") ? atoi(getenv("HALO_DOTS_FIRST")) : -1;  // development switch
+    const bool dots_first = dots_env >= 0 ? dots_env != 0 : (st->nofold ? st->M : m) > ((size_t)1 << 16);
+    auto launch_dots = [&]() -> int {
         hipStream_t saved = ctx->stream;
         ctx->stream = ctx->streams[2];
         int rcl = fr_dot2_launch(ctx, st->d_c + 4 * m, st->d_z, st->d_c, st->d_z + 4 * m, m);
         ctx->stream = saved;
-        if (rcl) return rcl;
-    }
+        return rcl;
+    };
+    if (dots_first) { int rcl = launch_dots(); if (rcl) return rcl; }
     if (st->nofold) {
         rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
         if (rc) return rc;
@@ -730,6 +735,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         rc = msm_enqueue(ctx, 1, st->d_G + 32 * m, st->d_c, true, m);
     }
     if (rc) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rc; }
+    if (!dots_first) { int rcl = launch_dots(); if (rcl) { host::Point dummy; (void)msm_finish(ctx, 0, &dummy); return rcl; } }
     double t1 = g_rt_on ? now_us() : 0;
     int rcd = fr_dot2_collect(ctx, ctx->streams[2], m, dots);
     // Window combine (~250 doublings), the H' term and the normalisation of L start on the helper thread as soon as L's
