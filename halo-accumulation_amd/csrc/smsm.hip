@@ -519,6 +519,12 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     // 64 quads per block, L buckets per quad, at most 16 segments per window
     uint32_t L = 1;
     while ((size_t)64 * L * 16 < p.B) L <<= 1;
+    {
+        // ... and no more blocks than give every SIMD one wave (4 waves per block): with 1.6 waves per SIMD the SIMDs that
+        // hold two ran every step of the chain at half speed, and the kernel waits for them
+        static const int waves_env = getenv("HALO_SMSM_WAVES") ? atoi(getenv("HALO_SMSM_WAVES")) : 1024;  // development switch (0: off)
+        while (waves_env > 0 && L < 64 && (size_t)Wt * ((p.B + 64 * L - 1) / (64 * L)) * 4 > (size_t)waves_env && (size_t)64 * L < p.B) L <<= 1;
+    }
     if (ctx->reduce_span > 0) {
         L = (uint32_t)ctx->reduce_span;
         while ((size_t)64 * L * 64 < p.B) L <<= 1;  // the final stage holds at most 64 segments
