@@ -2026,6 +2026,12 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         L = p.B >= 16384 ? 8 : p.B >= 4096 ? 4 : p.B >= 1024 ? 2 : 1;
         nseg = p.B / (64 * L);
     }
+    {
+        // no more waves than SIMDs (one wave each): a SIMD that holds two runs both chains at about half speed and the kernel
+        // waits for it (development switch HALO_REDUCE1_WAVES, 0 = off)
+        static const int waves_env = getenv("HALO_REDUCE1_WAVES") ? atoi(getenv("HALO_REDUCE1_WAVES")) : 1024;
+        while (waves_env > 0 && p.B > 64 && (size_t)Wt * nseg > (size_t)waves_env && nseg > 1 && L < 64) { L <<= 1; nseg >>= 1; }
+    }
     if (ctx->reduce_span > 0 && p.B > 64) {
         L = (uint32_t)ctx->reduce_span;
         while (64 * L > p.B) L >>= 1;
