@@ -35,4 +35,6 @@ print(json.dumps({"config": "ASDL over %d accumulated instances, n=2^%d, 1 GPU" 
                   "fast_check_s (K verifiers + 1 decider, benches/acc.rs:64-74)": t_ver + t_dec,
                   "verifier_ms_each": t_ver / K * 1e3, "decider_ms": t_dec * 1e3,
                   "slow_check_s (K deciders, benches/acc.rs:100-106, extrapolated from %d)" % min(K, 8): t_slow * K,
+                  "fold_table_build_ms (inside the chain: the second full-size open of the context builds the comb table, once)": ctx.info(2) / 1e3,
+                  "prover_chain_s_without_the_table_build": t_chain - ctx.info(2) / 1e6,
                   "all_accepted": True}))
