@@ -97,6 +97,9 @@ _SIGS = {
     "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_pcdl_check_partial": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u64p, u64p]),
+    "halo_pcdl_open_sharded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), u64p, C.c_size_t, C.c_size_t, u64p, C.c_size_t,
+                                         u64p, u64p, C.c_void_p, C.c_void_p, u64p, u64p]),
+    "halo_pcdl_check_sharded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, u64p, C.c_size_t, u64p, u64p, u64p, C.c_void_p, C.c_void_p]),
     "halo_acc_prover": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_verifier": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p]),
     "halo_acc_decider": (C.c_int, [C.c_void_p, u64p]),
@@ -533,6 +536,28 @@ def open_combine(parts, Hp, xi_prev):
     check(load().halo_open_combine(ptr(parts), parts.shape[0], ptr(np.ascontiguousarray(Hp, dtype=np.uint64)),
                                    ptr(np.ascontiguousarray(xi_prev, dtype=np.uint64)), ptr(L), ptr(R), ptr(xi), ptr(xi_inv)))
     return L, R, xi, xi_inv
+
+
+# the caller's all-gather as the library calls it (include/halo_accumulation.h halo_allgather_fn)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64))
+
+
+def make_allgather_callback(allgather, world: int):
+    """allgather(arr) -> (P, len) uint64 wrapped for halo_pcdl_open_sharded / _check_sharded; keep the returned object alive
+    for the duration of the call.  An exception inside the collective is kept in cb.error and reported as a failure."""
+    def _cb(_user, send, words, recv):
+        try:
+            a = np.ctypeslib.as_array(send, shape=(words,)).copy()
+            out = np.ascontiguousarray(allgather(a), dtype=np.uint64).reshape(-1)
+            assert out.size == world * words
+            np.ctypeslib.as_array(recv, shape=(world * words,))[:] = out
+            return 0
+        except Exception as e:  # noqa: BLE001 -- must not unwind through the C frame
+            cb.error = e
+            return 1
+    cb = ALLGATHER_FN(_cb)
+    cb.error = None
+    return cb
 
 
 def open_tail(recs, Hp, xi_prev):

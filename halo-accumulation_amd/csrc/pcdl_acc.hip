@@ -681,6 +681,120 @@ int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const
     return HALO_OK;
 }
 
+// ------------------------------------------------------------------ sharded open / check in one call each
+// The round loop of sharded.ShardedOpen (Python) in the library: G, c and the z-powers are placed cyclically (element i on
+// rank i mod P; the context is that rank's halo_ctx_create_urs_strided shard) and every collective of the open is one call
+// of the caller's all-gather: P x words in rank order.  What a rank exchanges: its share of p(z) (4 words; with the hiding
+// branch 16: the share of C_bar as well), per round L | R | dot_l | dot_r (32 words), at the end its last element of G, c
+// and z (20 words).  Every rank computes the same challenges and returns the same proof: the bytes of halo_pcdl_open.
+int halo_pcdl_open_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, uint64_t *rng_state, const uint64_t *coeffs_local, size_t len_local,
+                           size_t deg, const uint64_t C_w[12], size_t d, const uint64_t z_w[4], const uint64_t *w_w, halo_allgather_fn allgather,
+                           void *user, uint64_t *proof, uint64_t v_out[4]) {
+    HALO_CTX2(ctx);
+    if (!C_w || !z_w || !proof || !v_out || (len_local && !coeffs_local) || (w_w && !rng_state)) { set_error("open_sharded: null pointer"); return HALO_E_ARG; }
+    const size_t P = (size_t)stride;
+    if (P == 0 || !is_pow2(P) || offset >= stride || (P > 1 && !allgather)) { set_error("open_sharded: stride must be a power of two, offset below it, and an all-gather given"); return HALO_E_ARG; }
+    if (P > 64) { set_error("open_sharded: at most 64 ranks"); return HALO_E_ARG; }
+    size_t n = d + 1;
+    if (!is_pow2(n)) return fail_assert("open: d+1 is not a power of 2");  // pcdl.rs:130-132
+    if (n < P || n / P > ctx->n) return fail_assert("open: d > D");
+    const size_t nl = n / P, lg_n = ilog2(n), lg_l = ilog2(nl);
+    if (len_local > nl) return fail_assert("open: p.degree() > d");
+    std::memset(proof, 0, 8 * proof_words(lg_n));
+    proof[1] = lg_n;
+    auto gather = [&](const uint64_t *send, size_t words, std::vector<uint64_t> &recv) -> int {
+        recv.assign(P * words, 0);
+        if (!allgather) { std::memcpy(recv.data(), send, words * 8); return HALO_OK; }  // (one rank; with a callback the collective runs anyway)
+        int rc = allgather(user, send, words, recv.data());
+        if (rc) { set_error("open_sharded: the caller's all-gather failed"); return HALO_E_ARG; }
+        return HALO_OK;
+    };
+    halo_ipa *st = nullptr;
+    int rc = halo_ipa_begin_strided(ctx, nl, coeffs_local, len_local, z_w, stride, offset, &st);
+    if (rc) return rc;
+    std::unique_ptr<halo_ipa, void (*)(halo_ipa *)> guard(st, halo_ipa_destroy);
+    std::vector<uint64_t> recv;
+    uint64_t send[32];
+    rc = halo_ipa_dot_cz(st, send);  // this shard's share of p(z)   (:135)
+    if (rc) return rc;
+    uint64_t Cm[12];
+    std::memcpy(Cm, C_w, sizeof Cm);
+    if (w_w) {  // :137-164
+        rc = halo_ipa_hiding_partial(st, *rng_state, deg, z_w, stride, offset, send + 4);
+        if (rc) return rc;
+        rc = gather(send, 16, recv);
+        if (rc) return rc;
+        std::vector<uint64_t> v_parts(4 * P), cb_parts(12 * P);
+        for (size_t r = 0; r < P; ++r) { std::memcpy(&v_parts[4 * r], &recv[16 * r], 32); std::memcpy(&cb_parts[12 * r], &recv[16 * r + 4], 96); }
+        uint64_t alpha[4], Cprime[12];
+        rc = halo_open_hiding_combine(C_w, z_w, v_parts.data(), cb_parts.data(), P, w_w, rng_state, deg, pf_Cbar(proof, lg_n), alpha, pf_wp(proof, lg_n), Cprime);
+        if (rc) return rc;
+        rc = halo_ipa_apply_hiding(st, alpha);  // p' = p + alpha p_bar   (:156)
+        if (rc) return rc;
+        std::memcpy(Cm, Cprime, sizeof Cm);
+        proof[0] = 1;
+        recv.swap(v_parts);
+    } else {
+        Point::infinity().store(pf_Cbar(proof, lg_n));
+        rc = gather(send, 4, recv);
+        if (rc) return rc;
+    }
+    uint64_t xi[4], Hp[12];
+    rc = halo_open_start(Cm, z_w, recv.data(), P, v_out, xi, Hp);  // v, xi_0, H'   (:135, :180-181)
+    if (rc) return rc;
+    for (size_t round = 0; round < lg_l; ++round) {
+        rc = halo_ipa_round_lr_partial(st, send, send + 12, send + 24);
+        if (rc) return rc;
+        rc = gather(send, 32, recv);
+        if (rc) return rc;
+        uint64_t xn[4], xinv[4];
+        rc = halo_open_combine(recv.data(), P, Hp, xi, pf_L(proof, round), pf_R(proof, lg_n, round), xn, xinv);  // :203-213
+        if (rc) return rc;
+        std::memcpy(xi, xn, sizeof xi);
+        rc = halo_ipa_round_fold(st, xn, xinv);  // :216-224
+        if (rc) return rc;
+    }
+    uint64_t last[20];
+    rc = halo_ipa_finish_z(st, last, last + 12, last + 16);
+    if (rc) return rc;
+    if (P == 1) {
+        std::memcpy(pf_U(proof, lg_n), last, 96);
+        std::memcpy(pf_c(proof, lg_n), last + 12, 32);
+        return HALO_OK;
+    }
+    rc = gather(last, 20, recv);  // the P remaining elements, in index order
+    if (rc) return rc;
+    size_t lgP = ilog2(P);
+    std::vector<uint64_t> Ls(12 * lgP), Rs(12 * lgP);
+    rc = halo_open_tail(recv.data(), P, Hp, xi, Ls.data(), Rs.data(), pf_U(proof, lg_n), pf_c(proof, lg_n));  // the last lg P rounds
+    if (rc) return rc;
+    for (size_t k = 0; k < lgP; ++k) {
+        std::memcpy(pf_L(proof, lg_l + k), &Ls[12 * k], 96);
+        std::memcpy(pf_R(proof, lg_n, lg_l + k), &Rs[12 * k], 96);
+    }
+    return HALO_OK;
+}
+
+// pcdl::check over the same shards: halo_pcdl_check_partial, one all-gather of 12 words, the shares added in rank order,
+// U compared (pcdl.rs:338-339).  HALO_E_REJECT on every rank alike.
+int halo_pcdl_check_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
+                            const uint64_t *proof, halo_allgather_fn allgather, void *user) {
+    HALO_CTX2(ctx);
+    if (!C || !z || !v || !proof || (stride > 1 && !allgather)) { set_error("check_sharded: null pointer"); return HALO_E_ARG; }
+    Point U, part;
+    int rc = pcdl_check_partial_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof, stride, offset, &U, &part);
+    if (rc) return rc;
+    uint64_t send[12];
+    part.store_normalized(send);
+    std::vector<uint64_t> recv(12 * (size_t)stride);
+    if (!allgather) std::memcpy(recv.data(), send, sizeof send);
+    else if (allgather(user, send, 12, recv.data())) { set_error("check_sharded: the caller's all-gather failed"); return HALO_E_ARG; }
+    Point comm = Point::infinity();
+    for (uint64_t r = 0; r < stride; ++r) comm = comm + Point::load(&recv[12 * r]);
+    if (U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339
+    return HALO_OK;
+}
+
 // acc.rs:190-220
 int halo_acc_prover(halo_ctx *ctx, uint64_t *rng_state, size_t d, const uint64_t *qs, size_t m, uint64_t *acc) {
     HALO_CTX2(ctx);

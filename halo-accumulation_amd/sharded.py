@@ -18,6 +18,8 @@ crosses the fabric.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 
@@ -162,17 +164,47 @@ class ShardedOpen:
         self.ctx = self.lib.Context(urs_n=n // self.world, first_index=first_index + self.rank, stride=self.world, device=self.device)
         return self.ctx
 
+    def _callback(self):
+        cb = self.lib.make_allgather_callback(self.allgather, self.world) if self.allgather is not None else None
+        return cb, (C.cast(cb, C.c_void_p) if cb is not None else None)
+
+    def open(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
+        """pcdl::open over the sharded key in ONE library call (halo_pcdl_open_sharded): the round loop runs in the library,
+        every collective is a call back into self.allgather.  coeffs_local: this rank's coefficients c[r::P]; hiding
+        (pcdl.rs:137-164): the commitment randomness w, rng = [SplitMix64 state] (mutated, the same on every rank) and
+        deg = p.degree().  -> (proof, v); open_by_rounds is the same protocol spelled out call by call."""
+        from ._lib import check, ptr
+        if not self.coll:  # one rank, no forced collectives
+            cb, cbp = None, None
+        else:
+            cb, cbp = self._callback()
+        co = np.ascontiguousarray(coeffs_local, dtype=np.uint64).reshape(-1, 4)
+        lg_n = self.n.bit_length() - 1
+        proof = np.zeros(self.lib.load().halo_proof_words(lg_n), dtype=np.uint64)
+        v = np.zeros(4, dtype=np.uint64)
+        st = C.c_uint64(rng[0] if rng is not None else 0)
+        rc = self.lib.load().halo_pcdl_open_sharded(self.ctx.h, self.world, self.rank, C.byref(st), ptr(co), co.shape[0], int(deg or 0),
+                                                    ptr(np.ascontiguousarray(Cm, dtype=np.uint64)), self.n - 1, ptr(np.ascontiguousarray(z, dtype=np.uint64)),
+                                                    ptr(np.ascontiguousarray(w, dtype=np.uint64)) if w is not None else None, cbp, None, ptr(proof), ptr(v))
+        if cb is not None and cb.error is not None:
+            raise cb.error
+        check(rc)
+        if rng is not None and w is not None:
+            rng[0] = st.value
+        return proof, v
+
     def check(self, Cm, d, z, v, proof):
-        """pcdl::check (pcdl.rs:323-342) against the sharded key: every rank runs the succinct check (host arithmetic) and
-        commits to its own share of h's coefficients over its own points; one all-gather of 96 bytes per rank, the shares
-        added in rank order, U compared (:339).  Raises HaloReject like pcdl.check_proof, on every rank alike."""
-        from . import pcdl
-        from ._lib import HaloReject, point_sum
-        U, part = pcdl.check_partial(self.ctx, Cm, d, z, v, proof, self.world, self.rank)
-        parts = self.allgather(part) if self.coll else part[None]
-        comm = point_sum(parts)
-        if comm.tolist() != U.tolist():  # both normalised: (x, y, 1) or (1, 1, 0)
-            raise HaloReject("U != CM.Commit(ck, h_vec)")
+        """pcdl::check (pcdl.rs:323-342) against the sharded key in one library call (halo_pcdl_check_sharded): every rank
+        runs the succinct check (host arithmetic) and commits to its own share of h's coefficients over its own points;
+        one all-gather of 96 bytes per rank, the shares added in rank order, U compared (:339).  Raises HaloReject like
+        pcdl.check_proof, on every rank alike."""
+        from ._lib import check, ptr
+        cb, cbp = self._callback() if self.coll else (None, None)
+        a = lambda x: ptr(np.ascontiguousarray(x, dtype=np.uint64))
+        rc = self.lib.load().halo_pcdl_check_sharded(self.ctx.h, self.world, self.rank, a(Cm), d, a(z), a(v), a(proof), cbp, None)
+        if cb is not None and cb.error is not None:
+            raise cb.error
+        check(rc)
 
     def _rounds(self, ipa, count, Hp, xi, Ls, Rs, world):
         for _ in range(count):
@@ -184,8 +216,9 @@ class ShardedOpen:
             ipa.round_fold(xi, xi_inv)
         return xi
 
-    def open(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
-        """coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).
+    def open_by_rounds(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
+        """The protocol of `open` spelled out call by call from Python (what halo_pcdl_open_sharded does inside).
+        coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).
         Hiding (pcdl.rs:137-164): pass the commitment randomness w, rng = [SplitMix64 state] (mutated, the
         same on every rank) and deg = p.degree().  -> (proof, v)"""
         P, nl = self.world, self.n // self.world

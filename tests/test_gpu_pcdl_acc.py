@@ -642,6 +642,9 @@ def _sharded_worker(rank, world, port, n, q):
         C = Cs.numpy().view(np.uint64)
         rng = [4242]
         proof, v = so.open(np.ascontiguousarray(full[rank::world]), C, z[0], w=w, rng=rng, deg=n - 4)
+        rng2 = [4242]
+        proof_py, v_py = so.open_by_rounds(np.ascontiguousarray(full[rank::world]), C, z[0], w=w, rng=rng2, deg=n - 4)
+        ok = ok and proof_py.tolist() == proof.tolist() and v_py.tolist() == v.tolist() and rng2 == rng
         # pcdl::check against the sharded key: accepted by every rank; a proof with another U is rejected by every rank
         so.check(C, n - 1, z[0], v, proof)
         bad = proof.copy()
@@ -694,6 +697,9 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     proof, v = so.open(coeffs, C, z[0])
     assert proof.tolist() == pcdl.open(ctx, [1], coeffs, C, n - 1, z[0]).tolist()
     assert v.tolist() == ctx.poly_eval(coeffs, z[0]).tolist()
+    # the same protocol call by call from Python (what halo_pcdl_open_sharded runs inside)
+    proof2, v2 = so.open_by_rounds(coeffs, C, z[0])
+    assert proof2.tolist() == proof.tolist() and v2.tolist() == v.tolist()
     # hiding branch: same proof and same final rng state as pcdl::open
     w, _ = orc.rng_scalars(5, 1)
     Ch = pcdl.commit(ctx, coeffs, n - 1, w[0])
