@@ -30,6 +30,10 @@ pub const HALO_E_ARG: c_int = -3;
 pub const HALO_E_DEVICE: c_int = -4;
 
 #[link(name = "halo_hip")]
+/// every rank contributes `words` u64, `recv` receives P x words in rank order (e.g. a wrapper over `MPI_Allgather` or
+/// `ncclAllGather` + stream sync); 0 = success
+pub type HaloAllgatherFn = Option<unsafe extern "C" fn(user: *mut std::ffi::c_void, send: *const u64, words: usize, recv: *mut u64) -> c_int>;
+
 extern "C" {
     pub fn halo_last_error() -> *const c_char;
     pub fn halo_ctx_create(device: c_int, bases_affine: *const u64, n: usize, out: *mut *mut HaloCtx) -> c_int;
@@ -48,6 +52,13 @@ extern "C" {
     pub fn halo_ipa_round_fold(st: *mut HaloIpa, xi: *const u64, xi_inv: *const u64) -> c_int;
     pub fn halo_ipa_finish(st: *mut HaloIpa, u: *mut u64, c: *mut u64) -> c_int;
     pub fn halo_ipa_destroy(st: *mut HaloIpa);
+    // one process per GPU (MPI / RCCL ranks): the key placed cyclically, the collectives supplied by the caller
+    pub fn halo_ctx_create_urs_strided(device: c_int, first_index: u64, stride: u64, n: usize, out: *mut *mut HaloCtx) -> c_int;
+    pub fn halo_pcdl_open_sharded(ctx: *mut HaloCtx, stride: u64, offset: u64, rng_state: *mut u64, coeffs_local: *const u64, len_local: usize,
+                                  deg: usize, c: *const u64, d: usize, z: *const u64, w: *const u64, allgather: HaloAllgatherFn,
+                                  user: *mut std::ffi::c_void, proof_out: *mut u64, v_out: *mut u64) -> c_int;
+    pub fn halo_pcdl_check_sharded(ctx: *mut HaloCtx, stride: u64, offset: u64, c: *const u64, d: usize, z: *const u64, v: *const u64,
+                                   proof: *const u64, allgather: HaloAllgatherFn, user: *mut std::ffi::c_void) -> c_int;
 }
 
 // ---- limbs: exactly what `main.rs:47-53` prints (`x.0 .0` is the `[u64; 4]` Montgomery representation).
