@@ -709,6 +709,41 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     so.check(Ch, n - 1, z[0], v, proof)  # world 1: the whole of pcdl::check
 
 
+def test_sharded_entry_points_report_misuse_and_a_failing_collective(hal):
+    """halo_pcdl_open_sharded / _check_sharded: a stride that is no power of two, an offset past it, ranks without an
+    all-gather, and a collective that fails (a Python exception inside the callback must surface, not unwind the C frame)."""
+    from halo_accumulation_amd import pcdl
+    from halo_accumulation_amd.sharded import ShardedOpen
+    n = 64
+    coeffs, s = orc.rng_scalars(31, n)
+    z, _ = orc.rng_scalars(s, 1)
+    full = hal._lib.Context(urs_n=n)
+    C = pcdl.commit(full, coeffs, n - 1)
+    proof = pcdl.open(full, [1], coeffs, C, n - 1, z[0])
+    v = full.poly_eval(coeffs, z[0])
+
+    def broken(arr):
+        raise RuntimeError("fabric down")
+
+    so = ShardedOpen(hal._lib, 1, 2, broken)
+    so.load_key(n)
+    with pytest.raises(RuntimeError, match="fabric down"):
+        so.open(np.ascontiguousarray(coeffs[1::2]), C, z[0])
+    with pytest.raises(RuntimeError, match="fabric down"):
+        so.check(C, n - 1, z[0], v, proof)
+    lib = hal.load()
+    out, vv = np.zeros(hal.load().halo_proof_words(6), dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    a = lambda x: hal._lib.ptr(np.ascontiguousarray(x, dtype=np.uint64))
+    half = np.ascontiguousarray(coeffs[1::2])
+    for stride, offset in ((3, 0), (2, 2), (2, 1)):  # (2, 1) without an all-gather
+        rc = lib.halo_pcdl_open_sharded(so.ctx.h, stride, offset, None, a(half), half.shape[0], 0, a(C), n - 1, a(z[0]), None, None, None, a(out), a(vv))
+        assert rc != 0
+        rc = lib.halo_pcdl_check_sharded(so.ctx.h, stride, offset, a(C), n - 1, a(z[0]), a(v), a(proof), None, None)
+        assert rc != 0
+    so.ctx.close()
+    full.close()
+
+
 def test_check_partial_shares_add_up_to_the_commitment_of_h(hal):
     """halo_pcdl_check_partial on the P cyclic shards of a key (all on this one GPU): every rank returns the proof's U,
     and the P shares add up to CM.Commit(ck, h) = U (pcdl.rs:338-339) -- P = 1, 2, 8, and P = n (one point per rank)."""
