@@ -5,9 +5,9 @@
 // strings: ~128 doublings + ~213 mixed additions, ~3240 field products per output).  With
 //     E[w][d][i] = d * 64^w * G_i   (w < 22, d = 1..32, i in [n/4, n), affine, 64 bytes each, 44 KiB per point)
 // and the endomorphism (s = k1 + k2 lambda with |k1|, |k2| < 2^128, lambda (x, y) = (beta x, y): host_math.hpp glv_decompose)
-// a scalar multiple is 2 x 22 table entries added up (signed base-64 digits of k1 and k2; the k2 entries get their x
-// multiplied by beta), no doublings at all: ~128 mixed additions per output, ~1500 products -- the pass over 2^18 outputs
-// goes from 5.4 to ~2.6 ms.  The digits depend on the challenges only, i.e. they are the same for every lane of a wave:
+// a scalar multiple is 2 x 22 table entries added up (signed base-64 digits of k1 and k2; the k2 entries are summed as they
+// are and lambda is applied ONCE to their sum), no doublings at all: ~128 mixed additions per output, ~1350 products -- the
+// pass over 2^18 outputs goes from 5.4 to 2.45 ms.  The digits depend on the challenges only, i.e. they are the same for every lane of a wave:
 // entry (w, d) of consecutive points is read by consecutive lanes, so the layout [w][d][i] makes every gather a fully
 // coalesced 4 KiB read (2.1 GB per pass at n = 2^20).
 //
