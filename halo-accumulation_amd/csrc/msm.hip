@@ -15,6 +15,8 @@
 //   k_msm_combine_*   partials of multi-task buckets folded into the bucket value
 //   k_msm_reduce1     sum_k k*B_k per segment of a window: lane-local running sums + wave64 shuffle scans
 //   (k_smsm_final)    the segments of a window -> window sum (smsm.hip; quad-parallel, latency-bound)
+//   k_msm_reduce_rc   the table plans' form of the two: plain sums over the rows and columns of the bucket index (one set of
+//   (k_rc_mid)        buckets), weights applied to rows + columns points afterwards (smsm.hip), the last ~70 additions on the host
 //   host              Horner over the W window sums (240 doublings are a 60 us job for one CPU
 //                     core and a > 1 ms serial chain for one GPU lane)
 // msm_enqueue / msm_finish split the launch sequence from the final wait so that independent MSMs
