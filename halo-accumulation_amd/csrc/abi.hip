@@ -663,6 +663,14 @@ const host::FixedBaseTable &public_h_table() {
     }();
     return tbl;
 }
+const host::FixedBaseTable &public_s_table() {
+    static const host::FixedBaseTable tbl = [] {
+        uint64_t S[12], H[12];
+        halo_public_points(S, H);
+        return host::FixedBaseTable(host::Point::load(S));
+    }();
+    return tbl;
+}
 void ipa_set_hprime_scalar(halo_ipa *st, const host::Fr &xi0) {
     st->hp_from_scalar = true;
     st->hp_scalar = xi0;

@@ -74,7 +74,7 @@ static int pedersen_commit_dev(halo_ctx *ctx, const Fr *w, const uint64_t *d_ms,
     Point acc;
     int rc = msm_run(ctx, ctx->d_bases, d_ms, true, n, &acc);
     if (rc) return rc;
-    if (w) acc = public_points().S.mul(*w) + acc;
+    if (w) acc = public_s_table().mul(*w) + acc;
     *out = acc;
     return HALO_OK;
 }
@@ -88,7 +88,7 @@ static int commit_short_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, 
     std::vector<Fr> ks(len);
     for (size_t i = 0; i < len; ++i) { pts[i] = Point::load_affine(&bases[8 * i]); ks[i] = Fr::load(coeffs + 4 * i); }
     Point acc = host::small_msm(pts, ks);
-    if (w) acc = public_points().S.mul(*w) + acc;
+    if (w) acc = public_s_table().mul(*w) + acc;
     *out = acc;
     return HALO_OK;
 }
@@ -114,7 +114,6 @@ static int pcdl_commit_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, s
 static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point &C, size_t d, const Fr &z, const Fr *w,
                          uint64_t *proof) {
     size_t n = d + 1, lg_n = ilog2(n);
-    const PublicPoints &pp = public_points();
     std::memset(proof, 0, 8 * proof_words(lg_n));
     proof[1] = lg_n;
     Fr v;
@@ -138,7 +137,7 @@ static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point 
         rc = axpy_dev(ctx, ctx->d_poly, ctx->d_poly2, deg + 1, a);         // :156
         if (rc) return rc;
         Fr w_prime = w_bar * a + *w;                                       // :159
-        C_prime = C + C_bar.mul(a) - pp.S.mul(w_prime);                    // :162
+        C_prime = C + C_bar.mul(a) - public_s_table().mul(w_prime);                    // :162
         proof[0] = 1;
         C_bar.store_normalized(pf_Cbar(proof, lg_n));
         w_prime.store(pf_wp(proof, lg_n));
@@ -146,7 +145,7 @@ static int pcdl_open_dev(halo_ctx *ctx, host::Rng *rng, size_t deg, const Point 
         Point::infinity().store(pf_Cbar(proof, lg_n));
     }
     Fr xi = rho0_C_z_v(C_prime, z, v);  // :180
-    Point Hp = pp.H.mul(xi).normalized();  // :181
+    Point Hp = public_h_table().mul(xi).normalized();  // :181
     uint64_t Hp_w[12];
     Hp.store(Hp_w);
     halo_ipa *st = nullptr;
@@ -204,18 +203,17 @@ static int succinct_challenges(halo_ctx *ctx, const Point &C, size_t d, const Fr
     // `PallasPoint`/`PallasScalar` values are on the curve / below the modulus by construction, here that is checked.
     if (!C.on_curve() || !scalar_ok(z) || !scalar_ok(v)) return fail_reject("instance holds an invalid point or scalar");
     if (!proof_wellformed(proof, lg_n)) return fail_reject("proof holds an invalid point or scalar");
-    const PublicPoints &pp = public_points();
     st->lg_n = lg_n;
     st->C_prime = C;
     if (proof[0]) {
         Point C_bar = Point::load(pf_Cbar(proof, lg_n));
         Fr wp = Fr::load(pf_wp(proof, lg_n));
         Fr a = rho0_C_z_v_Cbar(C, z, v, C_bar);
-        st->C_prime = C + C_bar.mul(a) - pp.S.mul(wp);
+        st->C_prime = C + C_bar.mul(a) - public_s_table().mul(wp);
     }
     st->xis.assign(lg_n + 1, Fr::zero());
     st->xis[0] = rho0_C_z_v(st->C_prime, z, v);
-    if (need_hp) st->Hp = pp.H.mul(st->xis[0]);  // the batched relation multiplies H by (v - v') xi_0 instead
+    if (need_hp) st->Hp = public_h_table().mul(st->xis[0]);  // the batched relation multiplies H by (v - v') xi_0 instead
     for (size_t i = 0; i < lg_n; ++i) {
         st->xis[i + 1] = rho0_xi_L_R(st->xis[i], Point::load(pf_L(proof, i)), Point::load(pf_R(proof, lg_n, i)));
         if (st->xis[i + 1].is_zero()) return fail_reject("challenge is zero");
@@ -246,7 +244,19 @@ static int succinct_relation(const SuccinctState &st, const Fr &z, const Fr &v, 
         }
     }
     pts.push_back(st.Hp); ks.push_back(v);
-    Point C_i = st.C_prime + host::small_msm(pts, ks);  // :288-298
+    // :288-298.  2 lg n + 1 scalar multiples (~1.1 ms on one thread at lg n = 20): four interleaved-window sums on the host
+    // pool, added in order (the verifier's two instances run side by side: eight threads for ~0.35 ms)
+    Point C_i = st.C_prime;
+    {
+        const size_t ways = pts.size() >= 16 ? 4 : 1, per = (pts.size() + ways - 1) / ways;
+        std::vector<Point> part(ways, Point::infinity());
+        pool_run(ways, [&](size_t k) {
+            size_t lo = k * per, hi = lo + per < pts.size() ? lo + per : pts.size();
+            if (lo >= hi) return;
+            part[k] = host::small_msm(std::vector<Point>(pts.begin() + lo, pts.begin() + hi), std::vector<Fr>(ks.begin() + lo, ks.begin() + hi));
+        });
+        for (size_t k = 0; k < ways; ++k) C_i = C_i + part[k];
+    }
     // :301-304  v' = c * h(z)
     Fr c = Fr::load(pf_c(proof, lg_n));
     Fr hz = Fr::one() + xis[lg_n] * z, zi = z;
@@ -498,7 +508,7 @@ static int common_subroutine(halo_ctx *ctx, size_t d, const uint64_t *qs, size_t
     Transcript t2;
     t2.point(C); t2.scalar(hs->alpha);
     *z_out = t2.finish(1);                       // :181
-    *C_bar_out = C + public_points().S.mul(w);   // :184
+    *C_bar_out = C + public_s_table().mul(w);   // :184
     return HALO_OK;
 }
 
@@ -543,7 +553,7 @@ int halo_pedersen_commit_affine(halo_ctx *ctx, const uint64_t *w, const uint64_t
     int rc = halo_msm_affine(ctx, bases_affine, ms, n_ms, 1, acc_w);  // pedersen.rs:14 over the caller's generators
     if (rc) return rc;
     Point acc = Point::load(acc_w);
-    if (w) acc = public_points().S.mul(Fr::load(w)) + acc;  // pedersen.rs:15-17
+    if (w) acc = public_s_table().mul(Fr::load(w)) + acc;  // pedersen.rs:15-17
     acc.store_normalized(out);
     return HALO_OK;
 }
