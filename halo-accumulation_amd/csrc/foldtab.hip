@@ -238,6 +238,13 @@ static int foldtab_build(halo_ctx *ctx) {
         HALO_LAUNCH(ctx, "k_foldtab_build", k_foldtab_build, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->d_bases, (uint32_t)(lo + off),
                     (uint32_t)count, (uint32_t)lo, (uint32_t)cnt, tmp, tab);
         e = hipGetLastError();
+        if (debug_trace() && e == hipSuccess) {  // (tracing only: per-slice times, to see where a slow build spends it)
+            auto ts = std::chrono::steady_clock::now();
+            e = hipStreamSynchronize(ctx->stream);
+            fprintf(stderr, "[halo] fold table slice at %zu: %.1f ms since the build began (this wait %.1f ms)\n", off,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count());
+        }
     }
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = e2;
