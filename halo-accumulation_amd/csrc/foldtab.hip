@@ -216,6 +216,7 @@ void fold_digits_host(const host::Fr &s, int8_t out[2 * FT_WINDOWS]) {
 }
 
 void foldtab_release(halo_ctx *ctx) {
+    foldtab_cancel_alloc(ctx);
     if (!ctx->d_foldtab) return;
     alloc_epoch_bump(ctx);
     (void)hipFree(ctx->d_foldtab);
@@ -224,14 +225,27 @@ void foldtab_release(halo_ctx *ctx) {
 }
 
 // the table over [n/4, n) of the context's key, built in slices through a temporary of at most ~4 GiB
-static int foldtab_build(halo_ctx *ctx) {
+static size_t foldtab_slice(size_t cnt) { return cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15); }  // 32768 points x 704 entries x 200 B = 4.6 GB of temporaries
+static hipError_t foldtab_alloc(size_t n, uint32_t **tab, uint32_t **tmp) {
+    const size_t cnt = n - n / 4, bytes = (size_t)FT_ENTRIES * cnt * FT_WORDS * 4;
+    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(tab, bytes);
+    if (e == hipSuccess) e = hipMalloc(tmp, (size_t)FT_ENTRIES * foldtab_slice(cnt) * FT_TMP_WORDS * 4);
+    return e;
+}
+void foldtab_cancel_alloc(halo_ctx *ctx) {
+    if (ctx->foldtab_alloc_thread.joinable()) ctx->foldtab_alloc_thread.join();
+    if (ctx->foldtab_pending) (void)hipFree(ctx->foldtab_pending);
+    if (ctx->foldtab_pending_tmp) (void)hipFree(ctx->foldtab_pending_tmp);
+    ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
+    ctx->foldtab_alloc_state = 0;
+}
+// tab / tmp: buffers the helper thread obtained, or null (allocate here)
+static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp = nullptr) {
     const size_t N = ctx->n, lo = N / 4, cnt = N - lo;
     const size_t bytes = (size_t)FT_ENTRIES * cnt * FT_WORDS * 4;
     auto t0 = std::chrono::steady_clock::now();
-    uint32_t *tab = nullptr, *tmp = nullptr;
-    size_t slice = cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15);  // 32768 points x 704 entries x 200 B = 4.6 GB of temporaries
-    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tab, bytes);
-    if (e == hipSuccess) e = hipMalloc(&tmp, (size_t)FT_ENTRIES * slice * FT_TMP_WORDS * 4);
+    size_t slice = foldtab_slice(cnt);
+    hipError_t e = tab ? hipSuccess : foldtab_alloc(N, &tab, &tmp);
     const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (size_t off = 0; off < cnt && e == hipSuccess; off += slice) {
         size_t count = cnt - off < slice ? cnt - off : slice;
@@ -274,10 +288,34 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
         // mode 1: at the first full-size open; default: at the second (a context that opens once never pays the build)
         ctx->foldtab_opens++;
         // (automatic mode also stops at 2^21 points: 71 GB; larger keys on request only)
-        bool now = ctx->fold_table_mode == 1 ||
-                   (ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21) && ctx->foldtab_opens >= 2);
-        if (!now) return 0;
-        int rc = foldtab_build(ctx);
+        int rc;
+        if (ctx->fold_table_mode == 1) rc = foldtab_build(ctx);
+        else {
+            if (!(ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21))) return 0;
+            int st = ctx->foldtab_alloc_state.load(std::memory_order_acquire);
+            if (st == 0) {  // first full-size open: ask for the memory in the background; this open takes the generic kernel
+                ctx->foldtab_alloc_state = 1;
+                ctx->foldtab_alloc_thread = std::thread([ctx] {
+                    (void)hipSetDevice(ctx->device);
+                    hipError_t e = foldtab_alloc(ctx->n, &ctx->foldtab_pending, &ctx->foldtab_pending_tmp);
+                    if (e != hipSuccess) (void)hipGetLastError();
+                    ctx->foldtab_alloc_state.store(e == hipSuccess ? 2 : 3, std::memory_order_release);
+                });
+                return 0;
+            }
+            if (st == 1) return 0;  // not there yet: the generic kernel once more
+            ctx->foldtab_alloc_thread.join();
+            if (st == 3) {
+                foldtab_cancel_alloc(ctx);
+                ctx->fold_table_mode = 0;
+                fprintf(stderr, "[halo] fold table: no memory: this context continues without it\n");
+                return 0;
+            }
+            uint32_t *tab = ctx->foldtab_pending, *tmp = ctx->foldtab_pending_tmp;
+            ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
+            ctx->foldtab_alloc_state = 0;
+            rc = foldtab_build(ctx, tab, tmp);
+        }
         if (rc) return rc;
         if (!ctx->d_foldtab) return 0;
     }

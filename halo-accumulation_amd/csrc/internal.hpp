@@ -242,6 +242,12 @@ struct halo_ctx {
     size_t foldtab_bytes = 0;
     double foldtab_build_ms = 0;
     int foldtab_opens = 0;                 // full-size opens seen while the table did not exist
+    // automatic mode: the table's 40 GB are requested on a helper thread at the first full-size open (hipMalloc of that size
+    // takes 0.5 ms .. 2 s depending on what the driver has at hand) and the table is built at the first later open that
+    // finds them there.  state: 0 nothing, 1 running, 2 ready, 3 failed
+    std::thread foldtab_alloc_thread;
+    std::atomic<int> foldtab_alloc_state{0};
+    uint32_t *foldtab_pending = nullptr, *foldtab_pending_tmp = nullptr;
     int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
@@ -333,6 +339,7 @@ int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const u
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 
 // ---- foldtab.hip: the first two-level fold of an open from a comb table over the context's key
+void foldtab_cancel_alloc(halo_ctx *ctx);  // joins the helper thread and frees what it obtained
 int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]);  // 1 = done, 0 = not applicable
 void foldtab_release(halo_ctx *ctx);
 void fold_digits_host(const host::Fr &s, int8_t out[44]);

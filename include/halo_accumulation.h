@@ -301,8 +301,10 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 int halo_set_fold_levels(halo_ctx *ctx, int levels);
 /* IPA tuning: comb table for the first fold of an open whose size is the context's key (E[w][d][i] = d 64^w G_i: 22
  * windows x 32 multiples x 64 bytes per point of the upper three quarters of the key = 33 KiB x n: 35.4 GB at n = 2^20; ~0.2 s to
- * build; the scalars are split with the curve's endomorphism, 2 x 22 entries per scalar multiple).  -1 (default): built at the SECOND full-size open of a context of 2^18 .. 2^21 points (a prover chain, acc.rs:190-228,
- * opens twice per step; a single open never pays); 1: at the first; 0: never, and a table already built is released.
+ * build; the scalars are split with the curve's endomorphism, 2 x 22 entries per scalar multiple).  -1 (default), contexts of 2^18 .. 2^21 points: the first full-size open asks for the
+ * table's memory on a helper thread (40 GB at 2^20: 0.5 ms .. 2 s of hipMalloc depending on what the driver has at hand) and the
+ * first later open that finds it there builds the table -- a prover chain (acc.rs:190-228) opens twice per step, a single open
+ * never waits; 1: allocated and built at the first open; 0: never, a table already built (or requested) is released.
  * Results are identical; if the memory is not there the generic fold kernel runs. */
 int halo_set_fold_table(halo_ctx *ctx, int mode);
 /* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds the fold table took to build */

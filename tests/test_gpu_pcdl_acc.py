@@ -709,6 +709,51 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     so.check(Ch, n - 1, z[0], v, proof)  # world 1: the whole of pcdl::check
 
 
+def test_fold_table_automatic_mode_allocates_in_the_background(hal):
+    """Default mode on a context of >= 2^18 points: the first full-size open asks for the table's memory on a helper thread
+    and takes the generic fold; the table is built at the first later open that finds the memory there.  Every open returns
+    the same proof; closing a context while the request is still pending joins the thread and frees what it got."""
+    import time
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 18
+    d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        dv = torch.empty((n + 1) * 4, dtype=torch.int64, device="cuda")
+        c.rng_scalars_dev(0xF01D, n + 1, dv.data_ptr())
+        z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
+        C = pcdl.commit_dev(c, dv.data_ptr(), n, d)
+        first = pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z)
+        assert c.info(1) == 0, "the first open only asks for the memory"
+        built_at = None
+        for k in range(40):
+            p = pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z)
+            assert p.tolist() == first.tolist()
+            if c.info(1):
+                built_at = k
+                break
+            time.sleep(0.1)
+        assert built_at is not None and c.info(1) == 704 * 64 * (n - n // 4)
+        assert pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z).tolist() == first.tolist()  # through the table
+        c.set_fold_table(0)
+        assert c.info(1) == 0
+    finally:
+        c.close()
+    # a context closed (or told to do without) while its request may still be running
+    for how in ("close", "mode0"):
+        c2 = hal._lib.Context(urs_n=n)
+        dv = torch.empty((n + 1) * 4, dtype=torch.int64, device="cuda")
+        c2.rng_scalars_dev(0xF01D, n + 1, dv.data_ptr())
+        z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
+        C2 = pcdl.commit_dev(c2, dv.data_ptr(), n, d)
+        assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist()
+        if how == "mode0":
+            c2.set_fold_table(0)
+            assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist() and c2.info(1) == 0
+        c2.close()
+
+
 def test_sharded_entry_points_report_misuse_and_a_failing_collective(hal):
     """halo_pcdl_open_sharded / _check_sharded: a stride that is no power of two, an offset past it, ranks without an
     all-gather, and a collective that fails (a Python exception inside the callback must surface, not unwind the C frame)."""
