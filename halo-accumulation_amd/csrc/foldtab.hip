@@ -289,8 +289,19 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
         ctx->foldtab_opens++;
         // (automatic mode also stops at 2^21 points: 71 GB; larger keys on request only)
         int rc;
-        if (ctx->fold_table_mode == 1) rc = foldtab_build(ctx);
-        else {
+        if (ctx->fold_table_mode == 1) {
+            // (a request of the automatic mode may still be under way: wait for it and take what it brought)
+            uint32_t *tab = nullptr, *tmp = nullptr;
+            if (ctx->foldtab_alloc_state.load(std::memory_order_acquire) != 0) {
+                if (ctx->foldtab_alloc_thread.joinable()) ctx->foldtab_alloc_thread.join();
+                if (ctx->foldtab_alloc_state.load(std::memory_order_acquire) == 2) {
+                    tab = ctx->foldtab_pending; tmp = ctx->foldtab_pending_tmp;
+                    ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
+                    ctx->foldtab_alloc_state = 0;
+                } else foldtab_cancel_alloc(ctx);
+            }
+            rc = foldtab_build(ctx, tab, tmp);
+        } else {
             if (!(ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21))) return 0;
             int st = ctx->foldtab_alloc_state.load(std::memory_order_acquire);
             if (st == 0) {  // first full-size open: ask for the memory in the background; this open takes the generic kernel

@@ -741,7 +741,7 @@ def test_fold_table_automatic_mode_allocates_in_the_background(hal):
     finally:
         c.close()
     # a context closed (or told to do without) while its request may still be running
-    for how in ("close", "mode0"):
+    for how in ("close", "mode0", "mode1"):
         c2 = hal._lib.Context(urs_n=n)
         dv = torch.empty((n + 1) * 4, dtype=torch.int64, device="cuda")
         c2.rng_scalars_dev(0xF01D, n + 1, dv.data_ptr())
@@ -751,6 +751,9 @@ def test_fold_table_automatic_mode_allocates_in_the_background(hal):
         if how == "mode0":
             c2.set_fold_table(0)
             assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist() and c2.info(1) == 0
+        if how == "mode1":  # "at once": waits for the request under way and builds from what it brought
+            c2.set_fold_table(1)
+            assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist() and c2.info(1) > 0
         c2.close()
 
 
