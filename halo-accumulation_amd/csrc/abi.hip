@@ -1194,7 +1194,7 @@ int halo_set_fold_levels(halo_ctx *ctx, int levels) {
     return HALO_OK;
 }
 int halo_set_fold_table(halo_ctx *ctx, int mode) {
-    if (!ctx || mode < -1 || mode > 1) { set_error("fold table mode must be -1 (from the second full-size open), 0 (never) or 1 (at the first)"); return HALO_E_ARG; }
+    if (!ctx || mode < -1 || mode > 1) { set_error("fold table mode must be -1 (automatic), 0 (never) or 1 (at the first full-size open)"); return HALO_E_ARG; }
     if (mode == 0) {  // releases the table, and whatever the helper thread of the automatic mode has obtained
         HALO_CTX(ctx);
         for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
