@@ -173,3 +173,34 @@ def test_open_tail_reproduces_a_whole_open(hal):
     for bad in (3, 0, 128):
         with pytest.raises(hal._lib.HaloError):
             hal._lib.open_tail(np.zeros((bad, 20), dtype=np.uint64) if bad else np.zeros((0, 20), dtype=np.uint64), Hp, xi0)
+
+
+def test_open_combine_host_against_the_big_int_model(hal, urs4096):
+    """halo_open_combine (host only): L = sum L_i + (sum dot_l,i) H', R likewise, xi = rho_0(xi_prev, L, R), xi^-1 -- against
+    the Python big-int model, for two different H' in a row (the entry point keeps a window table of the last H' it saw)
+    and with an infinity among the partial points."""
+    import pallas_model as pm
+    P = 3
+    jac = np.zeros((8, 12), dtype=np.uint64)
+    for i in range(8):
+        orc.lib().orc_affine_to_jac(orc.ptr(urs4096[i]), orc.ptr(jac[i]))
+    aff = [orc.point_canonical(jac[i]) for i in range(8)]
+    rng = pm.SplitMix64(99)
+    for Hi in (6, 7, 6):
+        dots = [[rng.next_scalar() for _ in range(2)] for _ in range(P)]
+        xi_prev = rng.next_scalar()
+        parts = np.zeros((P, 32), dtype=np.uint64)
+        for r in range(P):
+            parts[r, :12] = jac[r]
+            parts[r, 12:24] = jac[3 + r]
+            parts[r, 24:28] = orc.fr_to_mont(dots[r][0])
+            parts[r, 28:32] = orc.fr_to_mont(dots[r][1])
+        parts[1, 0:4] = parts[1, 4:8] = jac[0, 8:12]; parts[1, 8:12] = 0  # L_1 = infinity, as the library writes it: (1, 1, 0)
+        L, R, xi, xi_inv = hal._lib.open_combine(parts, jac[Hi], orc.fr_to_mont(xi_prev))
+        dl = sum(d[0] for d in dots) % pm.R_ORDER
+        dr = sum(d[1] for d in dots) % pm.R_ORDER
+        Lw = pm.add(pm.add(aff[0], aff[2]), pm.mul(aff[Hi], dl))
+        Rw = pm.add(pm.add(pm.add(aff[3], aff[4]), aff[5]), pm.mul(aff[Hi], dr))
+        assert orc.point_canonical(L) == Lw and orc.point_canonical(R) == Rw
+        x = pm.rho_0(("s", xi_prev), ("p", Lw), ("p", Rw))
+        assert orc.fr_from_mont(xi) == x and orc.fr_from_mont(xi_inv) * x % pm.R_ORDER == 1
