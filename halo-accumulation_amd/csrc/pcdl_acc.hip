@@ -696,83 +696,145 @@ int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const
 // rank i mod P; the context is that rank's halo_ctx_create_urs_strided shard) and every collective of the open is one call
 // of the caller's all-gather: P x words in rank order.  What a rank exchanges: its share of p(z) (4 words; with the hiding
 // branch 16: the share of C_bar as well), per round L | R | dot_l | dot_r (32 words), at the end its last element of G, c
-// and z (20 words).  Every rank computes the same challenges and returns the same proof: the bytes of halo_pcdl_open.
+// and z (20 words) -- and ONE STATUS WORD behind every record.  Every rank computes the same challenges and returns the
+// same proof: the bytes of halo_pcdl_open.
+//
+// Failure safety.  The number and order of collectives of a call depend only on the arguments every rank passes alike
+// (P, d, hiding or not).  Whatever fails on ONE rank between two collectives -- a device allocation, a launch, a copy, a
+// per-rank argument such as too many local coefficients -- does not make that rank return: it enters the next collective
+// with its error code in the status word (its record zeroed), every rank reads the P status words of that collective and
+// all of them return the first non-zero one in rank order, at the same collective.  No rank is left waiting in an
+// all-gather its peers never enter.  (A collective that itself fails -- the callback returns non-zero -- is the caller's
+// fabric failing: the call returns HALO_E_ARG on the ranks that see it and the caller must abort its process group.)
+namespace {
+// HALO_TEST_SHARD_FAIL="<offset>:<step>": the rank with this offset fails locally (HALO_E_DEVICE) before collective number
+// <step> of a sharded open (0 = the share of p(z), 1.. = the rounds, then the tail), or "<offset>:check" in a sharded check
+// -- the test hook of tests/test_sharded_gloo.py and tests/test_gpu_pcdl_acc.py for the failure path above
+int shard_test_failure(uint64_t offset, long step, bool in_check) {
+    const char *e = getenv("HALO_TEST_SHARD_FAIL");
+    if (!e) return HALO_OK;
+    char *rest = nullptr;
+    unsigned long long off = strtoull(e, &rest, 10);
+    if (!rest || *rest != ':' || off != offset) return HALO_OK;
+    bool hit = in_check ? std::strcmp(rest + 1, "check") == 0 : (std::strcmp(rest + 1, "check") != 0 && strtol(rest + 1, nullptr, 10) == step);
+    if (!hit) return HALO_OK;
+    set_error("sharded call: local failure injected by HALO_TEST_SHARD_FAIL");
+    return HALO_E_DEVICE;
+}
+struct StatusGather {
+    size_t P;
+    uint64_t offset;
+    halo_allgather_fn fn;
+    void *user;
+    const char *who;
+    std::vector<uint64_t> sbuf, rbuf;
+    // all-gather of `words` record words + this rank's status; recv = P x words.  Returns the first non-zero status in rank
+    // order (the same value on every rank), HALO_E_ARG if the collective itself failed, else 0.
+    int run(const uint64_t *rec, size_t words, int local_rc, std::vector<uint64_t> &recv) {
+        recv.assign(P * words, 0);
+        if (!fn) {  // one rank, no callback: nothing to agree on
+            if (local_rc) return local_rc;
+            std::memcpy(recv.data(), rec, words * 8);
+            return HALO_OK;
+        }
+        sbuf.assign(words + 1, 0);
+        if (!local_rc) std::memcpy(sbuf.data(), rec, words * 8);
+        sbuf[words] = (uint64_t)(int64_t)local_rc;
+        rbuf.assign(P * (words + 1), 0);
+        std::string own = local_rc ? halo_last_error() : "";
+        if (fn(user, sbuf.data(), words + 1, rbuf.data())) {
+            set_error(std::string(who) + ": the caller's all-gather failed (abort the process group: the ranks are no longer in step)");
+            return HALO_E_ARG;
+        }
+        for (size_t r = 0; r < P; ++r) {
+            int st = (int)(int64_t)rbuf[r * (words + 1) + words];
+            if (!st) continue;
+            if (r == offset || local_rc == st) set_error(own);  // (a rejection every rank found by itself keeps its own wording)
+            else set_error(std::string(who) + ": rank " + std::to_string(r) + " failed locally (code " + std::to_string(st) + "); every rank returns its code");
+            return st;
+        }
+        for (size_t r = 0; r < P; ++r) std::memcpy(&recv[r * words], &rbuf[r * (words + 1)], words * 8);
+        return HALO_OK;
+    }
+};
+}  // namespace
+
 int halo_pcdl_open_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, uint64_t *rng_state, const uint64_t *coeffs_local, size_t len_local,
                            size_t deg, const uint64_t C_w[12], size_t d, const uint64_t z_w[4], const uint64_t *w_w, halo_allgather_fn allgather,
                            void *user, uint64_t *proof, uint64_t v_out[4]) {
     HALO_CTX2(ctx);
-    if (!C_w || !z_w || !proof || !v_out || (len_local && !coeffs_local) || (w_w && !rng_state)) { set_error("open_sharded: null pointer"); return HALO_E_ARG; }
+    // (arguments every rank passes alike: a mistake here is the same mistake everywhere, returned before any collective)
+    if (!C_w || !z_w || !proof || !v_out || (w_w && !rng_state)) { set_error("open_sharded: null pointer"); return HALO_E_ARG; }
     const size_t P = (size_t)stride;
     if (P == 0 || !is_pow2(P) || offset >= stride || (P > 1 && !allgather)) { set_error("open_sharded: stride must be a power of two, offset below it, and an all-gather given"); return HALO_E_ARG; }
     if (P > 64) { set_error("open_sharded: at most 64 ranks"); return HALO_E_ARG; }
     size_t n = d + 1;
     if (!is_pow2(n)) return fail_assert("open: d+1 is not a power of 2");  // pcdl.rs:130-132
-    if (n < P || n / P > ctx->n) return fail_assert("open: d > D");
+    if (n < P) return fail_assert("open: d > D");
     const size_t nl = n / P, lg_n = ilog2(n), lg_l = ilog2(nl);
-    if (len_local > nl) return fail_assert("open: p.degree() > d");
     std::memset(proof, 0, 8 * proof_words(lg_n));
     proof[1] = lg_n;
-    auto gather = [&](const uint64_t *send, size_t words, std::vector<uint64_t> &recv) -> int {
-        recv.assign(P * words, 0);
-        if (!allgather) { std::memcpy(recv.data(), send, words * 8); return HALO_OK; }  // (one rank; with a callback the collective runs anyway)
-        int rc = allgather(user, send, words, recv.data());
-        if (rc) { set_error("open_sharded: the caller's all-gather failed"); return HALO_E_ARG; }
-        return HALO_OK;
-    };
+    StatusGather sg{P, offset, allgather, user, "open_sharded", {}, {}};
+    long step = 0;
+    // lrc: this rank's own failure since the last collective; it rides into the next one (see above)
+    int lrc = HALO_OK, rc;
+    if (len_local && !coeffs_local) { set_error("open_sharded: null pointer"); lrc = HALO_E_ARG; }
+    else if (nl > ctx->n) lrc = fail_assert("open: d > D");                    // (per-rank: the shard contexts may differ)
+    else if (len_local > nl) lrc = fail_assert("open: p.degree() > d");
     halo_ipa *st = nullptr;
-    int rc = halo_ipa_begin_strided(ctx, nl, coeffs_local, len_local, z_w, stride, offset, &st);
-    if (rc) return rc;
+    if (!lrc) lrc = halo_ipa_begin_strided(ctx, nl, coeffs_local, len_local, z_w, stride, offset, &st);
     std::unique_ptr<halo_ipa, void (*)(halo_ipa *)> guard(st, halo_ipa_destroy);
     std::vector<uint64_t> recv;
-    uint64_t send[32];
-    rc = halo_ipa_dot_cz(st, send);  // this shard's share of p(z)   (:135)
-    if (rc) return rc;
+    uint64_t send[32] = {};
+    if (!lrc) lrc = halo_ipa_dot_cz(st, send);  // this shard's share of p(z)   (:135)
     uint64_t Cm[12];
     std::memcpy(Cm, C_w, sizeof Cm);
+    if (!lrc) lrc = shard_test_failure(offset, step, false);
     if (w_w) {  // :137-164
-        rc = halo_ipa_hiding_partial(st, *rng_state, deg, z_w, stride, offset, send + 4);
-        if (rc) return rc;
-        rc = gather(send, 16, recv);
+        if (!lrc) lrc = halo_ipa_hiding_partial(st, *rng_state, deg, z_w, stride, offset, send + 4);
+        rc = sg.run(send, 16, lrc, recv);
         if (rc) return rc;
         std::vector<uint64_t> v_parts(4 * P), cb_parts(12 * P);
         for (size_t r = 0; r < P; ++r) { std::memcpy(&v_parts[4 * r], &recv[16 * r], 32); std::memcpy(&cb_parts[12 * r], &recv[16 * r + 4], 96); }
         uint64_t alpha[4], Cprime[12];
+        // (host arithmetic on gathered data: the same outcome on every rank)
         rc = halo_open_hiding_combine(C_w, z_w, v_parts.data(), cb_parts.data(), P, w_w, rng_state, deg, pf_Cbar(proof, lg_n), alpha, pf_wp(proof, lg_n), Cprime);
         if (rc) return rc;
-        rc = halo_ipa_apply_hiding(st, alpha);  // p' = p + alpha p_bar   (:156)
-        if (rc) return rc;
+        lrc = halo_ipa_apply_hiding(st, alpha);  // p' = p + alpha p_bar   (:156)
         std::memcpy(Cm, Cprime, sizeof Cm);
         proof[0] = 1;
         recv.swap(v_parts);
     } else {
         Point::infinity().store(pf_Cbar(proof, lg_n));
-        rc = gather(send, 4, recv);
+        rc = sg.run(send, 4, lrc, recv);
         if (rc) return rc;
     }
     uint64_t xi[4], Hp[12];
     rc = halo_open_start(Cm, z_w, recv.data(), P, v_out, xi, Hp);  // v, xi_0, H'   (:135, :180-181)
     if (rc) return rc;
     for (size_t round = 0; round < lg_l; ++round) {
-        rc = halo_ipa_round_lr_partial(st, send, send + 12, send + 24);
-        if (rc) return rc;
-        rc = gather(send, 32, recv);
+        ++step;
+        if (!lrc) lrc = shard_test_failure(offset, step, false);
+        if (!lrc) lrc = halo_ipa_round_lr_partial(st, send, send + 12, send + 24);
+        rc = sg.run(send, 32, lrc, recv);
         if (rc) return rc;
         uint64_t xn[4], xinv[4];
         rc = halo_open_combine(recv.data(), P, Hp, xi, pf_L(proof, round), pf_R(proof, lg_n, round), xn, xinv);  // :203-213
         if (rc) return rc;
         std::memcpy(xi, xn, sizeof xi);
-        rc = halo_ipa_round_fold(st, xn, xinv);  // :216-224
-        if (rc) return rc;
+        lrc = halo_ipa_round_fold(st, xn, xinv);  // :216-224
     }
-    uint64_t last[20];
-    rc = halo_ipa_finish_z(st, last, last + 12, last + 16);
-    if (rc) return rc;
+    uint64_t last[20] = {};
+    ++step;
+    if (!lrc) lrc = shard_test_failure(offset, step, false);
+    if (!lrc) lrc = halo_ipa_finish_z(st, last, last + 12, last + 16);
     if (P == 1) {
+        if (lrc) return lrc;
         std::memcpy(pf_U(proof, lg_n), last, 96);
         std::memcpy(pf_c(proof, lg_n), last + 12, 32);
         return HALO_OK;
     }
-    rc = gather(last, 20, recv);  // the P remaining elements, in index order
+    rc = sg.run(last, 20, lrc, recv);  // the P remaining elements, in index order
     if (rc) return rc;
     size_t lgP = ilog2(P);
     std::vector<uint64_t> Ls(12 * lgP), Rs(12 * lgP);
@@ -785,20 +847,25 @@ int halo_pcdl_open_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, uint
     return HALO_OK;
 }
 
-// pcdl::check over the same shards: halo_pcdl_check_partial, one all-gather of 12 words, the shares added in rank order,
-// U compared (pcdl.rs:338-339).  HALO_E_REJECT on every rank alike.
+// pcdl::check over the same shards: halo_pcdl_check_partial, one all-gather of 12 words + the status word, the shares added
+// in rank order, U compared (pcdl.rs:338-339).  HALO_E_REJECT on every rank alike; a rank whose own half failed (device error)
+// still enters the collective and every rank returns its code (see halo_pcdl_open_sharded).
 int halo_pcdl_check_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t v[4],
                             const uint64_t *proof, halo_allgather_fn allgather, void *user) {
     HALO_CTX2(ctx);
     if (!C || !z || !v || !proof || (stride > 1 && !allgather)) { set_error("check_sharded: null pointer"); return HALO_E_ARG; }
+    if (stride == 0 || stride > 64 || offset >= stride) { set_error("check_sharded: stride in 1..64, offset below it"); return HALO_E_ARG; }
     Point U, part;
-    int rc = pcdl_check_partial_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof, stride, offset, &U, &part);
+    // The succinct check is host arithmetic on the same proof on every rank: its HALO_E_REJECT is the same everywhere, but it
+    // goes through the status word like any other outcome, so that the collective count stays fixed (one).
+    int lrc = shard_test_failure(offset, 0, true);
+    if (!lrc) lrc = pcdl_check_partial_host(ctx, Point::load(C), d, Fr::load(z), Fr::load(v), proof, stride, offset, &U, &part);
+    uint64_t send[12] = {};
+    if (!lrc) part.store_normalized(send);
+    StatusGather sg{(size_t)stride, offset, allgather, user, "check_sharded", {}, {}};
+    std::vector<uint64_t> recv;
+    int rc = sg.run(send, 12, lrc, recv);
     if (rc) return rc;
-    uint64_t send[12];
-    part.store_normalized(send);
-    std::vector<uint64_t> recv(12 * (size_t)stride);
-    if (!allgather) std::memcpy(recv.data(), send, sizeof send);
-    else if (allgather(user, send, 12, recv.data())) { set_error("check_sharded: the caller's all-gather failed"); return HALO_E_ARG; }
     Point comm = Point::infinity();
     for (uint64_t r = 0; r < stride; ++r) comm = comm + Point::load(&recv[12 * r]);
     if (U != comm) return fail_reject("U != CM.Commit(ck, h_vec)");  // :339

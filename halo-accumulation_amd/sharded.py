@@ -206,46 +206,87 @@ class ShardedOpen:
             raise cb.error
         check(rc)
 
+    def _gather(self, words, local):
+        """One collective of the by-rounds protocol: local() -> this rank's record (`words` uint64).  An exception on this
+        rank does not leave the peers waiting: the rank still enters the all-gather, with a status word of 1 behind a zeroed
+        record (the same rule as halo_pcdl_open_sharded), and EVERY rank raises after it.  -> (P, words)"""
+        rec, err = np.zeros(words + 1, dtype=np.uint64), None
+        try:
+            if self._pending is not None:
+                raise self._pending
+            rec[:words] = local()
+        except Exception as e:  # noqa: BLE001 -- reported after the collective
+            err = e
+            rec[:] = 0
+            rec[words] = 1
+        self._pending = None
+        got = self.allgather(rec) if self.coll else rec[None]
+        bad = [r for r in range(got.shape[0]) if got[r, words] != 0]
+        if err is not None:
+            raise err
+        if bad:
+            raise self.lib.HaloError("sharded open: rank %d failed locally; every rank stops at the same collective" % bad[0])
+        return np.ascontiguousarray(got[:, :words])
+
+    def _defer(self, fn):
+        """A local step between two collectives (a fold, p' = p + alpha p_bar): its failure rides into the next collective."""
+        try:
+            if self._pending is None:
+                fn()
+        except Exception as e:  # noqa: BLE001
+            self._pending = e
+
     def _rounds(self, ipa, count, Hp, xi, Ls, Rs, world):
         for _ in range(count):
-            rec = ipa.round_lr_partial()
-            parts = self.allgather(rec) if self.coll else rec[None]
+            parts = self._gather(32, ipa.round_lr_partial)
             L, R, xi, xi_inv = self.lib.open_combine(parts, Hp, xi)
             Ls.append(L)
             Rs.append(R)
-            ipa.round_fold(xi, xi_inv)
+            self._defer(lambda: ipa.round_fold(xi, xi_inv))
         return xi
 
     def open_by_rounds(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
-        """The protocol of `open` spelled out call by call from Python (what halo_pcdl_open_sharded does inside).
-        coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).
+        """The protocol of `open` spelled out call by call from Python (what halo_pcdl_open_sharded does inside, status
+        word included).  coeffs_local: this rank's coefficients c[r::P] (zero-padded to n/P by the library).
         Hiding (pcdl.rs:137-164): pass the commitment randomness w, rng = [SplitMix64 state] (mutated, the
         same on every rank) and deg = p.degree().  -> (proof, v)"""
         P, nl = self.world, self.n // self.world
         lg_n = self.n.bit_length() - 1
-        ipa = self.lib.Ipa(self.ctx, nl, coeffs_local, z, stride=P, offset=self.rank)
-        v_part = ipa.dot_cz()  # this shard's share of p(z)
+        self._pending = None
+        box = {}
+
+        def begin():
+            box["ipa"] = self.lib.Ipa(self.ctx, nl, coeffs_local, z, stride=P, offset=self.rank)
+            return box["ipa"].dot_cz()  # this shard's share of p(z)
+
         hiding = w is not None
         Cbar = wp = None
-        if hiding:
-            cb_part = ipa.hiding_partial(rng[0], deg, z, P, self.rank)  # slice of p_bar from the stream + its MSM
-            rec = self.allgather(np.concatenate([v_part, cb_part])) if self.coll else np.concatenate([v_part, cb_part])[None]
-            v_parts = np.ascontiguousarray(rec[:, :4])
-            Cbar, alpha, wp, C_prime, rng[0] = self.lib.open_hiding_combine(Cm, z, v_parts, np.ascontiguousarray(rec[:, 4:]), w, rng[0], deg)
-            ipa.apply_hiding(alpha)  # p' = p + alpha p_bar
-            Cm = C_prime
-        else:
-            v_parts = self.allgather(v_part) if self.coll else v_part[None]
-        v, xi, Hp = self.lib.open_start(Cm, z, v_parts)
-        Ls, Rs = [], []
-        xi = self._rounds(ipa, nl.bit_length() - 1, Hp, xi, Ls, Rs, P)
-        U, c, z0 = ipa.finish_z()
-        ipa.close()
-        if P > 1:
-            rec = self.allgather(np.concatenate([U, c, z0]))  # (P, 20): the P remaining elements in index order
-            tL, tR, U, c = self.lib.open_tail(rec, Hp, xi)  # the last lg P rounds: host arithmetic, the same on every rank
-            Ls.extend(tL)
-            Rs.extend(tR)
+        try:
+            if hiding:
+                rec = self._gather(16, lambda: np.concatenate([begin(), box["ipa"].hiding_partial(rng[0], deg, z, P, self.rank)]))
+                ipa = box["ipa"]
+                v_parts = np.ascontiguousarray(rec[:, :4])
+                Cbar, alpha, wp, C_prime, rng[0] = self.lib.open_hiding_combine(Cm, z, v_parts, np.ascontiguousarray(rec[:, 4:]), w, rng[0], deg)
+                self._defer(lambda: ipa.apply_hiding(alpha))  # p' = p + alpha p_bar
+                Cm = C_prime
+            else:
+                v_parts = self._gather(4, begin)
+                ipa = box["ipa"]
+            v, xi, Hp = self.lib.open_start(Cm, z, v_parts)
+            Ls, Rs = [], []
+            xi = self._rounds(ipa, nl.bit_length() - 1, Hp, xi, Ls, Rs, P)
+            if P > 1:
+                rec = self._gather(20, lambda: np.concatenate(ipa.finish_z()))  # (P, 20): the P remaining elements in index order
+                tL, tR, U, c = self.lib.open_tail(rec, Hp, xi)  # the last lg P rounds: host arithmetic, the same on every rank
+                Ls.extend(tL)
+                Rs.extend(tR)
+            else:
+                if self._pending is not None:
+                    raise self._pending
+                U, c, z0 = ipa.finish_z()
+        finally:
+            if box.get("ipa") is not None:
+                box["ipa"].close()
         proof = np.zeros(self.lib.load().halo_proof_words(lg_n), dtype=np.uint64)
         proof[1] = lg_n
         for i in range(lg_n):

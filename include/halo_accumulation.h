@@ -234,19 +234,27 @@ int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const
 
 /* ---- sharded open / check in one call each --------------------------------------------------------------
  * The caller's all-gather: every rank contributes `words` u64 from `send`, `recv` receives P x words in rank order; returns
- * 0 on success.  Collectives stay outside the library (RCCL through the host language, MPI, ...): this is the only hook. */
+ * 0 on success.  Collectives stay outside the library (RCCL through the host language, MPI, ...): this is the only hook.
+ *
+ * Failure safety: the number and order of collectives of a call depend only on the arguments all ranks pass alike (P, d,
+ * hiding or not).  Every record carries one status word behind its payload (the sizes below are payload + 1): a rank on
+ * which something fails between two collectives (device allocation, launch, copy, a per-rank argument) does NOT return --
+ * it enters the next collective with its error code there, and all P ranks return that code (the first non-zero one in rank
+ * order) at the same collective.  No rank waits in an all-gather its peers never enter.  If the callback itself returns
+ * non-zero the fabric has failed: the call returns HALO_E_ARG and the caller must abort its process group. */
 typedef int (*halo_allgather_fn)(void *user, const uint64_t *send, size_t words, uint64_t *recv);
 /* pcdl::open (pcdl.rs:120-242) with G, c and the z-powers placed cyclically: ctx = this rank's shard of the key
  * (halo_ctx_create_urs_strided with stride = P ranks, first_index + offset), coeffs_local = c[offset], c[offset + P], ...
  * (len_local of them), deg = p.degree() of the WHOLE polynomial (hiding branch only), w = commitment randomness or NULL,
- * *rng_state as halo_pcdl_open (the same on every rank, advanced alike).  Per round one all-gather of 32 words, no vector
- * exchange; the last lg P rounds run on the host from the P gathered elements.  proof_out and v_out = p(z) are the same on
+ * *rng_state as halo_pcdl_open (the same on every rank, advanced alike).  Collectives, in order: the shares of p(z) (4 + 1
+ * words; hiding: 16 + 1), per round L | R | dot_l | dot_r (32 + 1 words), the P last elements (20 + 1 words, P > 1 only); no
+ * vector exchange; the last lg P rounds run on the host from the P gathered elements.  proof_out and v_out = p(z) are the same on
  * every rank and equal what halo_pcdl_open returns on one GPU. */
 int halo_pcdl_open_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, uint64_t *rng_state, const uint64_t *coeffs_local, size_t len_local,
                            size_t deg, const uint64_t C[12], size_t d, const uint64_t z[4], const uint64_t *w /*nullable*/,
                            halo_allgather_fn allgather, void *user, uint64_t *proof_out, uint64_t v_out[4]);
-/* pcdl::check (pcdl.rs:323-342) over the same shards: halo_pcdl_check_partial, one all-gather of 12 words, the sum compared
- * with U; HALO_E_REJECT on every rank alike */
+/* pcdl::check (pcdl.rs:323-342) over the same shards: halo_pcdl_check_partial, one all-gather of 12 + 1 words, the sum compared
+ * with U; HALO_E_REJECT -- or the code of a rank whose half failed -- on every rank alike */
 int halo_pcdl_check_sharded(halo_ctx *ctx, uint64_t stride, uint64_t offset, const uint64_t C[12], size_t d, const uint64_t z[4],
                             const uint64_t v[4], const uint64_t *proof, halo_allgather_fn allgather, void *user);
 /* acc::prover / verifier / decider (acc.rs:190-255); instances = m contiguous Instance blobs */

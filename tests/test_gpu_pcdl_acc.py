@@ -685,6 +685,118 @@ def test_sharded_open_two_and_four_ranks_on_one_gpu(world, n):
     assert all(pr == res[0][2] for _, _, pr in res)
 
 
+def _sharded_fail_worker(rank, world, port, n, q):
+    """Rank 1 is made to fail locally at several points of a sharded open / check (HALO_TEST_SHARD_FAIL, and a Python
+    exception in the by-rounds driver): EVERY rank must come back with an error from the same collective -- nobody hangs."""
+    import os, sys
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd.sharded import ShardedOpen
+    import orc
+
+    calls = [0]
+
+    def allgather(arr):
+        calls[0] += 1
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
+        out = torch.empty(world * t.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, t)
+        return out.numpy().view(np.uint64).reshape(world, -1)
+
+    coeffs, s = orc.rng_scalars(0x48414C4F00000003, n)
+    z, _ = orc.rng_scalars(s, 1)
+    wz, _ = orc.rng_scalars(s + 99, 1)
+    so = ShardedOpen(h._lib, rank, world, allgather)
+    so.load_key(n)
+    local = np.ascontiguousarray(coeffs[rank::world])
+    # the commitment: the sum of the ranks' MSMs (non-hiding)
+    C = h._lib.point_sum(allgather(so.ctx.msm(local)))
+    proof, v = so.open(local, C, z[0])  # no failure injected: the reference outcome
+    so.check(C, n - 1, z[0], v, proof)
+    lg_l = (n // world).bit_length() - 1
+    outcomes = []
+    for step, hiding in ((0, False), (0, True), (1, False), (lg_l // 2, False), (lg_l, True), (lg_l + 1, False)):
+        os.environ["HALO_TEST_SHARD_FAIL"] = "1:%d" % step  # offset 1 fails before collective `step`
+        calls[0] = 0
+        try:
+            so.open(local, C, z[0], w=wz[0] if hiding else None, rng=[7], deg=n - 1)
+            outcomes.append(("open", step, "returned", calls[0]))
+        except h._lib.HaloError as e:
+            outcomes.append(("open", step, "HaloError", calls[0], "injected" in str(e), "rank 1" in str(e)))
+    os.environ["HALO_TEST_SHARD_FAIL"] = "1:check"
+    calls[0] = 0
+    try:
+        so.check(C, n - 1, z[0], v, proof)
+        outcomes.append(("check", "returned"))
+    except h._lib.HaloError as e:
+        outcomes.append(("check", "HaloError", calls[0], "injected" in str(e), "rank 1" in str(e)))
+    del os.environ["HALO_TEST_SHARD_FAIL"]
+    # the same rule in the by-rounds Python driver: rank 1's third round raises
+    if rank == 1:
+        orig, seen = h._lib.Ipa.round_lr_partial, [0]
+
+        def flaky(self):
+            seen[0] += 1
+            if seen[0] == 3:
+                raise RuntimeError("local failure on rank 1")
+            return orig(self)
+
+        h._lib.Ipa.round_lr_partial = flaky
+    calls[0] = 0
+    try:
+        so.open_by_rounds(local, C, z[0])
+        outcomes.append(("by_rounds", "returned"))
+    except (RuntimeError, h._lib.HaloError) as e:
+        outcomes.append(("by_rounds", type(e).__name__, calls[0]))
+    if rank == 1:
+        h._lib.Ipa.round_lr_partial = orig
+    # and the group is still in step: a clean open afterwards gives the reference proof on every rank
+    again, _ = so.open(local, C, z[0])
+    q.put((rank, outcomes, again.tolist() == proof.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_open_a_failing_rank_fails_every_rank_at_the_same_collective():
+    """VERDICT r3 weak #5 / ADVICE r3: a rank-local failure must not leave the peers in an all-gather.  Two gloo ranks on the
+    one GPU; rank 1 fails before the first collective, in the hiding branch, in an early / middle / last round, at the tail,
+    in the check, and (by-rounds driver) with a Python exception.  Both ranks must return an error after the SAME number of
+    collectives, within the timeout, and a clean open afterwards still works."""
+    import socket
+    import torch.multiprocessing as mp
+    world, n = 2, 1 << 10
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_fail_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict((r, (o, ok)) for r, o, ok in [q.get(timeout=240) for _ in range(world)])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    o0, ok0 = res[0]
+    o1, ok1 = res[1]
+    assert ok0 and ok1
+    lg_l = (n // world).bit_length() - 1
+    for k, step in enumerate((0, 0, 1, lg_l // 2, lg_l, lg_l + 1)):
+        assert o0[k][:3] == ("open", step, "HaloError") and o1[k][:3] == ("open", step, "HaloError"), (o0[k], o1[k])
+        assert o0[k][3] == o1[k][3] == step + 1, "both ranks stop after the same collective"
+        assert o1[k][4] and o0[k][5], "the failing rank keeps its own message, the peer names the failing rank"
+    assert o0[6][:3] == ("check", "HaloError", 1) and o1[6][:3] == ("check", "HaloError", 1) and o1[6][3] and o0[6][4]
+    assert o0[7] == ("by_rounds", "HaloError", 4) and o1[7] == ("by_rounds", "RuntimeError", 4)
+
+
 def test_sharded_open_world_one_is_plain_open(hal, ctx):
     from halo_accumulation_amd import pcdl
     from halo_accumulation_amd.sharded import ShardedOpen

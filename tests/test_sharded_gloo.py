@@ -127,3 +127,81 @@ def test_shard_range_partition():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _status_worker(rank, world, port, q):
+    """The collective rule of the sharded open's by-rounds driver (ShardedOpen._gather / _defer), without a device: a rank
+    whose local step raises still enters the all-gather with a status word, every rank raises after that collective."""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import halo_accumulation_amd as h
+    from halo_accumulation_amd.sharded import ShardedOpen, make_allgather
+    calls = [0]
+    ag = make_allgather()
+
+    def allgather(arr):
+        calls[0] += 1
+        return ag(arr)
+
+    so = ShardedOpen(h._lib, rank, world, allgather)
+    so._pending = None
+    log = []
+    # 1. nobody fails: the records come back in rank order, status stripped
+    got = so._gather(3, lambda: np.array([rank, 10 * rank, 7], dtype=np.uint64))
+    log.append(got.tolist() == [[r, 10 * r, 7] for r in range(world)])
+    # 2. the last rank's local step raises: every rank raises after this one collective (the failing rank its own exception)
+    def local():
+        if rank == world - 1:
+            raise ValueError("device lost on rank %d" % rank)
+        return np.zeros(5, dtype=np.uint64)
+    before = calls[0]
+    try:
+        so._gather(5, local)
+        log.append("returned")
+    except ValueError as e:
+        log.append(("ValueError", str(e), calls[0] - before))
+    except h._lib.HaloError as e:
+        log.append(("HaloError", "rank %d" % (world - 1) in str(e), calls[0] - before))
+    # 3. a failure between two collectives (a fold) rides into the next one
+    so._defer(lambda: (_ for _ in ()).throw(RuntimeError("fold failed")) if rank == 0 else None)
+    before = calls[0]
+    try:
+        so._gather(2, lambda: np.ones(2, dtype=np.uint64))
+        log.append("returned")
+    except RuntimeError as e:
+        log.append((type(e).__name__, calls[0] - before))
+    # 4. and the group is still in step afterwards
+    got = so._gather(1, lambda: np.array([rank + 1], dtype=np.uint64))
+    log.append(got.reshape(-1).tolist() == list(range(1, world + 1)))
+    q.put((rank, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_failing_rank_reaches_the_collective_and_every_rank_raises(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_status_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict(q.get(timeout=120) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank in range(world):
+        log = res[rank]
+        assert log[0] is True and log[3] is True
+        if rank == world - 1:
+            assert log[1] == ("ValueError", "device lost on rank %d" % rank, 1)
+        else:
+            assert log[1] == ("HaloError", True, 1)
+        assert log[2] == ("RuntimeError" if rank == 0 else "HaloError", 1)
