@@ -1,6 +1,6 @@
 //! `code/src/ffi.rs` -- binding of libhalo_hip.so (include/halo_accumulation.h) for rasmus-kirk/halo-accumulation.
 //!
-//! Drop this file into `code/src/` and apply `lib_rs.patch` (`mod ffi;`), `group_rs.patch` and `pcdl_rs.patch`.
+//! Drop this file into `code/src/` and apply `lib_rs.patch` (`mod ffi;`), `group_rs.patch`, `pcdl_rs.patch` and `acc_rs.patch`.
 //! `build.rs` next to it tells cargo where the library is.  NOT COMPILED in the build image of this repository
 //! (no Rust toolchain there): the C side is exercised through the identical C ABI by `integration/harness.c`
 //! and by the ctypes binding of the parity tests.
@@ -9,7 +9,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 use std::sync::OnceLock;
 
-use ark_ff::{BigInt, PrimeField};
+use ark_ff::BigInt;
 
 use crate::consts::{GS, N};
 use crate::group::{PallasAffine, PallasPoint, PallasScalar};
@@ -29,14 +29,15 @@ pub const HALO_E_REJECT: c_int = -2; // -> bail!    (reference: ensure!)
 pub const HALO_E_ARG: c_int = -3;
 pub const HALO_E_DEVICE: c_int = -4;
 
-#[link(name = "halo_hip")]
 /// every rank contributes `words` u64, `recv` receives P x words in rank order (e.g. a wrapper over `MPI_Allgather` or
 /// `ncclAllGather` + stream sync); 0 = success
-pub type HaloAllgatherFn = Option<unsafe extern "C" fn(user: *mut std::ffi::c_void, send: *const u64, words: usize, recv: *mut u64) -> c_int>;
+pub type HaloAllgatherFn = Option<unsafe extern "C" fn(user: *mut c_void, send: *const u64, words: usize, recv: *mut u64) -> c_int>;
 
+#[link(name = "halo_hip")]
 extern "C" {
     pub fn halo_last_error() -> *const c_char;
     pub fn halo_ctx_create(device: c_int, bases_affine: *const u64, n: usize, out: *mut *mut HaloCtx) -> c_int;
+    pub fn halo_ctx_create_multi(devices: *const c_int, n_dev: c_int, bases_affine: *const u64, n: usize, out: *mut *mut HaloCtx) -> c_int;
     pub fn halo_ctx_destroy(ctx: *mut HaloCtx);
     pub fn halo_msm(ctx: *mut HaloCtx, off: usize, n: usize, scalars: *const u64, mont: c_int, out_jac: *mut u64) -> c_int;
     pub fn halo_msm_points(ctx: *mut HaloCtx, pts_jac: *const u64, scalars: *const u64, m: usize, out_jac: *mut u64) -> c_int;
@@ -47,6 +48,7 @@ extern "C" {
     pub fn halo_h_coeffs(ctx: *mut HaloCtx, xis: *const u64, lg_n: usize, out: *mut u64) -> c_int;
     pub fn halo_h_commit(ctx: *mut HaloCtx, xis: *const u64, lg_n: usize, out_jac: *mut u64) -> c_int;
     pub fn halo_h_eval_batch(ctx: *mut HaloCtx, xis: *const u64, m: usize, lg_n: usize, z: *const u64, out: *mut u64) -> c_int;
+    pub fn halo_h_accumulate(ctx: *mut HaloCtx, h0: *const u64, xis: *const u64, alphas: *const u64, m: usize, lg_n: usize, out: *mut u64) -> c_int;
     pub fn halo_ipa_begin(ctx: *mut HaloCtx, n: usize, coeffs: *const u64, len: usize, z: *const u64, out: *mut *mut HaloIpa) -> c_int;
     pub fn halo_ipa_round_lr(st: *mut HaloIpa, h_prime: *const u64, l: *mut u64, r: *mut u64) -> c_int;
     pub fn halo_ipa_round_fold(st: *mut HaloIpa, xi: *const u64, xi_inv: *const u64) -> c_int;
@@ -56,9 +58,9 @@ extern "C" {
     pub fn halo_ctx_create_urs_strided(device: c_int, first_index: u64, stride: u64, n: usize, out: *mut *mut HaloCtx) -> c_int;
     pub fn halo_pcdl_open_sharded(ctx: *mut HaloCtx, stride: u64, offset: u64, rng_state: *mut u64, coeffs_local: *const u64, len_local: usize,
                                   deg: usize, c: *const u64, d: usize, z: *const u64, w: *const u64, allgather: HaloAllgatherFn,
-                                  user: *mut std::ffi::c_void, proof_out: *mut u64, v_out: *mut u64) -> c_int;
+                                  user: *mut c_void, proof_out: *mut u64, v_out: *mut u64) -> c_int;
     pub fn halo_pcdl_check_sharded(ctx: *mut HaloCtx, stride: u64, offset: u64, c: *const u64, d: usize, z: *const u64, v: *const u64,
-                                   proof: *const u64, allgather: HaloAllgatherFn, user: *mut std::ffi::c_void) -> c_int;
+                                   proof: *const u64, allgather: HaloAllgatherFn, user: *mut c_void) -> c_int;
 }
 
 // ---- limbs: exactly what `main.rs:47-53` prints (`x.0 .0` is the `[u64; 4]` Montgomery representation).
@@ -103,13 +105,24 @@ pub fn ensure_ok(rc: c_int) -> anyhow::Result<()> {
     }
 }
 
-/// one context per process for the constant key (`consts.rs:68` is a process-global constant)
+/// One context per process for the constant key (`consts.rs:68` is a process-global constant).
+/// `HALO_DEVICES=0,1,2,3` (comma-separated HIP device ids, in the environment of the process): ONE process drives several
+/// GPUs of the node through a multi-device context (`halo_ctx_create_multi`: a full context on the first device plus one
+/// index-block shard per listed device) -- the MSMs behind `point_dot_affine` and the commits inside `pcdl` fan out, nothing
+/// else in this file changes.  Unset, or one id: a plain context on that device (default 0).
 pub fn ctx() -> *mut HaloCtx {
     static CTX: OnceLock<usize> = OnceLock::new();
     *CTX.get_or_init(|| {
         let mut c = std::ptr::null_mut();
         let limbs = aff_limbs(&KEY);
-        ck(unsafe { halo_ctx_create(0, limbs.as_ptr(), KEY.len(), &mut c) });
+        let devices: Vec<c_int> = std::env::var("HALO_DEVICES")
+            .map(|s| s.split(',').filter_map(|t| t.trim().parse().ok()).collect())
+            .unwrap_or_default();
+        if devices.len() > 1 {
+            ck(unsafe { halo_ctx_create_multi(devices.as_ptr(), devices.len() as c_int, limbs.as_ptr(), KEY.len(), &mut c) });
+        } else {
+            ck(unsafe { halo_ctx_create(devices.first().copied().unwrap_or(0), limbs.as_ptr(), KEY.len(), &mut c) });
+        }
         c as usize
     }) as *mut HaloCtx
 }
@@ -160,6 +173,34 @@ pub fn h_commit(xis: &[PallasScalar]) -> PallasPoint {
     point_from(out)
 }
 
+// ---- AccumulatedHPolys (acc.rs:69-107) ---------------------------------------------------------------------------
+/// the challenges of m polynomials h_i, (lg n + 1) scalars each, back to back
+fn xis_limbs(xis: &[&[PallasScalar]]) -> (Vec<u64>, usize) {
+    let per = xis.first().map_or(1, |x| x.len());
+    assert!(per >= 1 && xis.iter().all(|x| x.len() == per), "the accumulated h polynomials have one degree bound (acc.rs:158-166)");
+    (xis.iter().flat_map(|x| fr_limbs(x)).collect(), per - 1)
+}
+/// `AccumulatedHPolys::get_poly` (acc.rs:85-94): the coefficients of h_0 + sum_i alphas[i] h_i(X), every h_i expanded from
+/// its challenges on the device in O(n) (the reference multiplies lg n dense polynomials per h_i).  `h0` = the coefficients
+/// of the linear polynomial h_0 (0, 1 or 2 of them: DensePolynomial drops leading zeros); `alphas[i]` belongs to `xis[i]`.
+pub fn h_accumulate(h0: &[PallasScalar], xis: &[&[PallasScalar]], alphas: &[PallasScalar]) -> Vec<PallasScalar> {
+    assert!(h0.len() <= 2 && alphas.len() == xis.len() && !xis.is_empty());
+    let (xl, lg_n) = xis_limbs(xis);
+    let mut h0l = fr_limbs(h0);
+    h0l.resize(8, 0); // zero in Montgomery form is all-zero limbs
+    let mut out = vec![0u64; 4 << lg_n];
+    ck(unsafe { halo_h_accumulate(ctx(), h0l.as_ptr(), xl.as_ptr(), fr_limbs(alphas).as_ptr(), xis.len(), lg_n, out.as_mut_ptr()) });
+    out.chunks_exact(4).map(|w| scalar_from([w[0], w[1], w[2], w[3]])).collect()
+}
+/// `HPoly::eval` (pcdl.rs:79-91) of m polynomials at one point, as `AccumulatedHPolys::eval` needs them (acc.rs:102-104)
+pub fn h_eval_batch(xis: &[&[PallasScalar]], z: &PallasScalar) -> Vec<PallasScalar> {
+    if xis.is_empty() { return Vec::new(); }
+    let (xl, lg_n) = xis_limbs(xis);
+    let mut out = vec![0u64; 4 * xis.len()];
+    ck(unsafe { halo_h_eval_batch(ctx(), xl.as_ptr(), xis.len(), lg_n, z.0 .0.as_ptr(), out.as_mut_ptr()) });
+    out.chunks_exact(4).map(|w| scalar_from([w[0], w[1], w[2], w[3]])).collect()
+}
+
 // ---- the halving loop of pcdl::open (pcdl.rs:183-231) --------------------------------------------------------------
 pub struct Ipa(*mut HaloIpa);
 impl Ipa {
@@ -188,4 +229,3 @@ impl Ipa {
 }
 impl Drop for Ipa { fn drop(&mut self) { unsafe { halo_ipa_destroy(self.0) } } }
 
-#[allow(unused)] fn _types(_: *mut c_void, _: &dyn PrimeField) {}

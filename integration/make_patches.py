@@ -66,6 +66,32 @@ def edit_pcdl(src):
     return apply(s, edits, src)
 
 
+def edit_acc(src):
+    """AccumulatedHPolys::get_poly / eval (acc.rs:85-106): m x lg n dense-polynomial products on one core -> one O(n)
+    expansion per h_i on the device (halo_h_accumulate), and the m evaluations in one launch (halo_h_eval_batch)"""
+    s = open(src).read()
+    edits = [
+        (lines(src, 86, 93),
+         "        if self.hs.is_empty() {\n"
+         "            return self.h_0.clone().unwrap_or_else(PallasPoly::zero);\n"
+         "        }\n"
+         "        // h_0 + sum_i alpha^(i+1) h_i(X): every h_i expanded from its challenges on the device, O(n) each\n"
+         "        let h_0: &[PallasScalar] = match &self.h_0 {\n"
+         "            Some(h_0) => h_0.coeffs.as_slice(),\n"
+         "            None => &[],\n"
+         "        };\n"
+         "        let xis: Vec<&[PallasScalar]> = self.hs.iter().map(|h| h.xis.as_slice()).collect();\n"
+         "        let alphas = &self.alphas[1..=self.hs.len()];\n"
+         "        PallasPoly::from_coefficients_vec(crate::ffi::h_accumulate(h_0, &xis, alphas))\n"),
+        (lines(src, 102, 104),
+         "        let xis: Vec<&[PallasScalar]> = self.hs.iter().map(|h| h.xis.as_slice()).collect();\n"
+         "        for (i, h_i_z) in crate::ffi::h_eval_batch(&xis, z).iter().enumerate() {\n"
+         "            v += *h_i_z * self.alphas[i + 1];\n"
+         "        }\n"),
+    ]
+    return apply(s, edits, src)
+
+
 def edit_lib(src):
     s = open(src).read()
     return apply(s, [(lines(src, 2, 3), "mod consts;\nmod ffi;\npub mod group;\n")], src)
@@ -97,5 +123,6 @@ def make(rel, editor, out_name):
 if __name__ == "__main__":
     make("code/src/group.rs", edit_group, "group_rs.patch")
     make("code/src/pcdl.rs", edit_pcdl, "pcdl_rs.patch")
+    make("code/src/acc.rs", edit_acc, "acc_rs.patch")
     make("code/src/lib.rs", edit_lib, "lib_rs.patch")
-    print("wrote group_rs.patch, pcdl_rs.patch, lib_rs.patch")
+    print("wrote group_rs.patch, pcdl_rs.patch, acc_rs.patch, lib_rs.patch")
