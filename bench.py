@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--open-steps J]
 
+However it is started it prints one line: under torch.distributed.run (WORLD_SIZE set) it is one rank of N; started plainly
+with --gpus N > 1 it drives the N GPUs from this ONE process through a multi-device context (as with --one-process).
+
 A step = one MSM over n random scalars (resident in HBM) and the URS bases G_0..G_{n-1}
 (derived on the GPU by the reference's main.rs rule).  N > 1 (launched by torch.distributed.run,
 one rank per GPU): the SAME n-point MSMs are sharded -- by Pippenger windows (default: every rank keeps
@@ -54,6 +57,9 @@ def main():
     ap.add_argument("--host-steps", type=int, default=8, help="MSMs with the scalars in host memory (halo_msm and its begin/end halves) at N=1 (0 = skip)")
     ap.add_argument("--fr-reps", type=int, default=20, help="back-to-back launches of each bandwidth-side Fr kernel at N=1 (0 = skip)")
     ap.add_argument("--asdl-steps", type=int, default=8, help="ASDL chain steps (random_instance + prover + verifier, then one decider) at N=1 (0 = skip)")
+    ap.add_argument("--var-steps", type=int, default=60, help="MSMs through the table-free (variable-base) pipeline at N=1 (0 = skip)")
+    ap.add_argument("--cpu-log-n", type=int, default=14, help="size of the CPU baseline of open + check and of the ASDL chain (the reference's own D + 1 = 2^14, consts.rs:23)")
+    ap.add_argument("--concurrent-opens", type=int, default=2, help="open + check pairs in flight on separate contexts / host threads for the throughput figure at N=1 (0 or 1 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,12 +79,21 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend=backend)
-    one_proc = args.one_process
-    assert world == (1 if one_proc else args.gpus), "launch with torch.distributed.run --nproc-per-node == --gpus (or --one-process)"
-    devices = None
+    # --gpus N runs however it is started: under a launcher (WORLD_SIZE in the environment) this process is one rank of N;
+    # started plainly it drives all N GPUs itself through a multi-device context (halo_ctx_create_urs_multi) -- no launcher,
+    # no re-exec.  With fewer than N GPUs on the box the device ids repeat (a rehearsal: config.sharding says so).
+    launched = "WORLD_SIZE" in os.environ
+    one_proc = args.one_process or (args.gpus > 1 and not launched)
+    assert world == (1 if one_proc else args.gpus), "under torch.distributed.run --nproc-per-node must equal --gpus"
+    devices, devices_note = None, ""
     if one_proc:
-        devices = [int(x) for x in args.devices.split(",")] if args.devices else [k % max(torch.cuda.device_count(), 1) for k in range(args.gpus)]
+        have = max(torch.cuda.device_count(), 1)
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else [k % have for k in range(args.gpus)]
         assert len(devices) == args.gpus
+        if not args.one_process:
+            devices_note = "started without a launcher (WORLD_SIZE unset): "
+        if len(set(devices)) < len(devices):
+            devices_note += "REHEARSAL, device ids repeat (%d GPU(s) visible): " % have
         gpu = devices[0]
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
@@ -295,7 +310,7 @@ def main():
             "timed_region": {"repetitions": len(reps), "reported": "median", "seconds_each": [round(x, 6) for x in reps[:32]]},
             "dtype": "u32x8 (256-bit Montgomery integer)", "data": "synthetic",
             "config": {"workload": "Pippenger MSM n=2^%d, bases = URS G_i by main.rs rule, scalars SplitMix64 seed 0x48414C4F00000002" % args.log_n,
-                       "sharding": ("one process, multi-device context: %d index-block shards on devices %s, partial points added on the host "
+                       "sharding": (devices_note + "one process, multi-device context: %d index-block shards on devices %s, partial points added on the host "
                                     "(no collective)" % (len(devices), devices)) if one_proc and args.gpus > 1 else "single GPU" if world == 1 else
                                    ("Pippenger windows split over the ranks (key + scalars replicated), %s all-gather of 96 B partials" % coll_name if window_mode
                                     else "block index shard per rank + %s all-gather of 96 B partials" % coll_name),
@@ -327,14 +342,19 @@ def main():
         result["sharded_equals_single_gpu"] = ok
         assert ok, "multi-device MSM differs from the single-GPU MSM"
     elif world == 1:
-        # bit-exactness in the same run + CPU baseline (oracle = single-thread port of the arkworks path)
-        gs = ctx.read_bases()
+        # Everything below runs on the GPU only; the CPU restatement (oracle/) is touched in ONE leg at the very end, which
+        # times it on the host cores as the reported baseline and compares what the GPU produced above with it, bit for bit.
         cpu_model = "unknown"
         try:
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
         sc_host = np.ascontiguousarray(d_sets[0].cpu().numpy().view(np.uint64).reshape(n, 4))
+        gpu_side = {}  # what the CPU leg compares: inputs and GPU outputs of the small (2^cpu_log_n) open / ASDL runs
+
+        def median(xs):
+            return sorted(xs)[len(xs) // 2]
+
         if args.host_steps > 0:
             # the same MSM with the scalars handed over in HOST memory (halo_msm: 32 MiB H2D per MSM at n = 2^20, pageable):
             # the PCIe-inclusive rate; never `value`
@@ -367,42 +387,56 @@ def main():
                                                  "note": "halo_msm: %d MiB of scalars copied from pageable host memory each call, one MSM in flight (a call is "
                                                          "the copy + the latency of one MSM); pipelined: halo_msm_begin/_end on %d slots, the next copy under the "
                                                          "current kernels; h2d_copy_alone: the same buffer through torch, for scale" % (sc_host.nbytes >> 20, D)}
-        if args.cpu_msms > 0:
-            import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
-            sc_all = sc_host
-            assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
-            t0 = time.perf_counter()
-            for _ in range(args.cpu_msms):
-                want = orc.msm_affine(gs, sc_all)
-            cpu_dt = (time.perf_counter() - t0) / args.cpu_msms
-            assert out.tolist() == want.tolist(), "GPU MSM differs from the CPU restatement"
-            result["bit_exact_vs_cpu"] = True
-            # the same port on all the host cores this process may use: independent MSMs, one per thread (ctypes releases the
-            # GIL); a reported figure next to the single-thread one, which is how the reference runs
-            import threading
-            try:
-                T = len(os.sched_getaffinity(0))
-            except Exception:
-                T = os.cpu_count() or 1
-            T = max(1, min(T, 64))
-            box = [None] * T
-
-            def one(k):
-                box[k] = orc.msm_affine(gs, sc_all)
-
-            t0 = time.perf_counter()
-            ths = [threading.Thread(target=one, args=(k,)) for k in range(T)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-            par_dt = time.perf_counter() - t0
-            assert all(b.tolist() == want.tolist() for b in box)
-            result["cpu_baseline_all_cores"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port", "cpu_model": cpu_model,
-                                                "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
-            result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
-                                      "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
-                                      "host_cpus": os.cpu_count()}
+        if args.var_steps > 0 and not window_mode:
+            # VARIABLE-BASE figure (group.rs:24-26 is VariableBaseMSM::msm_unchecked): the same MSM, same loop, with the fixed-base
+            # table switched off (halo_set_table_mode(ctx, 0) releases it) -- the general pipeline, which is what halo_msm_affine,
+            # point_dot, every folded key of the IPA and every generator that is not the context's key get.
+            ctx.set_table_mode(0)
+            var_first = ctx.msm_dev(ptrs[0], n)
+            assert var_first.tolist() == out.tolist(), "general pipeline differs from the table pipeline"
+            run_steps(3 * args.depth)
+            vreps = []
+            while sum(vreps) < 0.4 and len(vreps) < 20:
+                barrier()
+                t0 = time.perf_counter()
+                run_steps(args.var_steps)
+                barrier()
+                vreps.append(time.perf_counter() - t0)
+            vdt = median(vreps)
+            vsolo = []
+            for _ in range(8):
+                t0 = time.perf_counter()
+                ctx.msm_dev(ptrs[0], n)
+                vsolo.append(time.perf_counter() - t0)
+            cfg["depth"] = 1
+            ctx.prof_enable(2); ctx.prof_reset()
+            run_steps(8)
+            vprof = ctx.prof()
+            ctx.prof_enable(0)
+            cfg["depth"] = args.depth
+            vk_ms = vprof.get("k_msm_accumulate", (0.0, 0))[0] / 8
+            vtraffic, vsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_general.json")
+            if args.log_n == 20 and os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                vtraffic = pj["kernels"].get("k_msm_accumulate", {}).get("traffic_bytes_per_launch")
+                vsrc = "static: profiles/r04_pmc_traffic_general.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+            vach = (96 * n + 64) / (vk_ms * 1e-3) / 1e9 if vk_ms > 0 else 0.0
+            result["variable_base"] = {
+                "value": args.var_steps / vdt, "unit": "MSM/s", "ms_per_step": vdt / args.var_steps * 1e3, "solo_latency_ms": median(vsolo) * 1e3,
+                "steps": args.var_steps, "repetitions": len(vreps), "launches_in_flight": args.depth,
+                "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": vach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": vach / HBM_PEAK_GBS,
+                             "kernel_ms": vk_ms, "algorithmic_bytes": 96 * n + 64, "traffic": vtraffic, "traffic_source": vsrc},
+                "hbm_roofline_frac_whole_msm": (args.var_steps / vdt) * (96 * n + 64) / (HBM_PEAK_GBS * 1e9),
+                "note": "halo_set_table_mode(ctx, 0): no fixed-base table -- the general Pippenger pipeline (signed windows of <= 16 bits, one bucket set "
+                        "per window), the same %d-point MSM over the same key and scalars, same result (asserted); this is the rate of halo_msm_affine / "
+                        "point_dot / the IPA's folded keys, minus their upload" % n}
+            ctx.set_table_mode(-1)
+            assert ctx.msm_dev(ptrs[0], n).tolist() == out.tolist()  # (the table is rebuilt here, untimed)
+        small_n = 1 << min(args.cpu_log_n, args.log_n)
+        ctx_small = None
+        if (args.open_steps > 0 or args.asdl_steps > 0) and args.cpu_msms > 0:
+            ctx_small = ctx if small_n == n else h._lib.Context(urs_n=small_n, device=gpu)
         if args.open_steps > 0:
             # BASELINE configs[2]: pcdl::open + check at the same n.  Compute-only = the polynomial already resident in device
             # memory (halo_pcdl_open_dev); end-to-end = coefficients handed over in pageable host memory (halo_pcdl_open).
@@ -413,47 +447,166 @@ def main():
             coeffs, zw = np.ascontiguousarray(co[:n]), np.ascontiguousarray(co[n:])
             C = pcdl.commit_dev(ctx, d_co.data_ptr(), n, d)
             assert C.tolist() == pcdl.commit(ctx, coeffs, d).tolist()
-            # warm-up: the first full-size open of a context asks for the fold table's memory on a helper thread, the first
-            # later open that finds it there builds the table (foldtab.hip); the timed opens run with the table in place
-            pi = pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
-            for _ in range(40):
-                pi = pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
-                if ctx.info(1) or n < (1 << 18) or n > (1 << 21):
-                    break
-                time.sleep(0.1)
-            pi = pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
             v = ctx.poly_eval(coeffs, zw[0])
 
-            def timed(fn):
+            def one(c_=None):
+                p_ = pcdl.open_dev(c_ or ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
+                pcdl.check_proof(c_ or ctx, C, d, zw[0], v, p_)
+                return p_
+
+            def timed(fn, reps):
                 torch.cuda.synchronize()
-                ts = []
-                for _ in range(args.open_steps):
+                ts, p_ = [], None
+                for _ in range(reps):
                     t0 = time.perf_counter()
                     p_ = fn()
-                    pcdl.check_proof(ctx, C, d, zw[0], v, p_)
                     ts.append(time.perf_counter() - t0)
-                return sorted(ts)[len(ts) // 2], p_, ts
+                return ts, p_
 
-            _, pi, ts_a = timed(lambda: pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0]))
-            hdt, pi_h, _ = timed(lambda: pcdl.open(ctx, [1], coeffs, C, d, zw[0]))
-            assert pi.tolist() == pi_h.tolist()
-            _, _, ts_b = timed(lambda: pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0]))  # second set, after the host path
+            # (a) WITHOUT the fold table (halo_set_fold_table(ctx, 0): the price list of the 35 GB): the first open of the context
+            # (it allocates the IPA buffers), then the steady state
+            ctx.set_fold_table(0)
+            (t_first_open,), pi0 = timed(one, 1)
+            one()
+            ts_plain, pi_plain = timed(one, args.open_steps)
+            assert pi_plain.tolist() == pi0.tolist()
+            # (b) WITH it, asked for explicitly (mode 1: allocated and built at the next open; the default mode -1 asks for the memory
+            # on a helper thread at the first full-size open and builds at the first later open that finds it)
+            ctx.set_fold_table(1)
+            (t_build_open,), pi_b = timed(one, 1)
+            assert pi_b.tolist() == pi0.tolist()
+            table_in_place = ctx.info(1) > 0
+            ts_a, pi = timed(one, args.open_steps)
+            hts, pi_h = timed(lambda: (lambda p_: (pcdl.check_proof(ctx, C, d, zw[0], v, p_), p_)[1])(pcdl.open(ctx, [1], coeffs, C, d, zw[0])), args.open_steps)
+            hdt = median(hts)
+            assert pi.tolist() == pi_h.tolist() == pi0.tolist()
+            ts_b, _ = timed(one, args.open_steps)  # second set, after the host-path runs
             pooled = sorted(ts_a + ts_b)
             odt = pooled[len(pooled) // 2]  # ONE median over both sets of samples (not the better of two medians)
-            ctx.prof_enable(2); ctx.prof_reset()  # one more open with event brackets around the fold kernels
+            plain_dt = median(ts_plain)
+            # check alone, and the kernels of one open with event brackets around every launch
+            cts, _ = timed(lambda: pcdl.check_proof(ctx, C, d, zw[0], v, pi), max(args.open_steps, 3))
+            ctx.prof_enable(1); ctx.prof_reset()
             pcdl.open_dev(ctx, [1], d_co.data_ptr(), n, C, d, zw[0])
-            prof = ctx.prof()
+            oprof = ctx.prof()
             ctx.prof_enable(0)
-            fold_ms = sum(ms for k, (ms, cnt) in prof.items() if k.startswith("k_fold_points"))
+            fold_ms = sum(ms for k, (ms, cnt) in oprof.items() if k.startswith("k_fold_points"))
+            by_time = sorted(((ms, k, cnt) for k, (ms, cnt) in oprof.items()), reverse=True)
+            # Roofline of the open's dominant kernel = its longest single launch: the first two-level fold of G (pcdl.rs:216-219 applied
+            # twice, n -> n / 4 points).  ALGORITHMIC bytes of that fold: n points of 64 B read, n / 4 written = 80 n.
+            dom_o = max(((ms / max(cnt, 1), k) for k, (ms, cnt) in oprof.items() if k.startswith("k_fold_points")), default=(0.0, None))
+            o_roof = None
+            if dom_o[1]:
+                o_ms, o_alg = dom_o[0], 80 * n
+                o_traffic, o_src = None, None
+                pmc = os.path.join(ROOT, "profiles", "r04_pmc_open_loop.json")
+                if args.log_n == 20 and table_in_place and os.path.exists(pmc):
+                    pj = json.load(open(pmc))
+                    o_traffic = pj["kernels"].get("k_fold_tab4", {}).get("traffic_bytes_per_launch")
+                    o_src = "static: profiles/r04_pmc_open_loop.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/open_loop.py")
+                o_ach = o_alg / (o_ms * 1e-3) / 1e9 if o_ms > 0 else 0.0
+                # VALU view: a table fold is ~128 mixed additions per output (2 x 22 comb entries per scalar, three scalars) of ~1143
+                # v_mad_u64_u32 each (the XYZZ mixed addition of the bucket kernel), n / 4 outputs
+                props_o = torch.cuda.get_device_properties(gpu)
+                peak_o = props_o.multi_processor_count * 4 * 2.4e9 / 5.26
+                adds_per_out = 3 * 44 + 1 if dom_o[1] == "k_fold_points4_tab" else None
+                valu_o = None
+                if adds_per_out and o_ms > 0:
+                    wm = (n // 4) * adds_per_out * 1143 / 64
+                    valu_o = {"unit": "v_mad_u64_u32 wave-instr/s", "achieved": wm / (o_ms * 1e-3), "peak": peak_o, "frac": wm / (o_ms * 1e-3) / peak_o,
+                              "mixed_additions_per_output": adds_per_out}
+                o_roof = {"bound": "hbm", "kernel": dom_o[1], "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": o_ach / HBM_PEAK_GBS,
+                          "kernel_ms": o_ms, "algorithmic_bytes": o_alg, "traffic": o_traffic, "traffic_source": o_src, "valu": valu_o,
+                          "note": "integer-VALU-bound like the MSM's bucket kernel: the comb-table fold reads its 2.1 GB of table entries as "
+                                  "coalesced 4 KiB gathers; see DESIGN.md 4.1"}
+            gain = plain_dt - odt
             result["pcdl_open_check"] = {"value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False,
                                           "algorithmic_bytes": 480 * n, "hbm_roofline_frac": (480 * n / odt) / (HBM_PEAK_GBS * 1e9),
+                                          "roofline": o_roof,
+                                          "check_alone_ms": median(cts) * 1e3,
+                                          "kernels_of_one_open_ms": {k: {"ms": round(ms, 4), "launches": cnt} for ms, k, cnt in by_time[:8]},
                                           "k_fold_points_ms_per_open": fold_ms,
+                                          "fold_table_in_place": table_in_place, "fold_table_status": ctx.info(5),
                                           "fold_table_bytes": ctx.info(1), "fold_table_build_ms": ctx.info(2) / 1e3,
+                                          "without_fold_table_ms": plain_dt * 1e3, "first_open_of_the_context_ms": t_first_open * 1e3,
+                                          "open_that_builds_the_table_ms": t_build_open * 1e3,
+                                          "fold_table_break_even_opens": (t_build_open - plain_dt) / gain if gain > 0 else None,
+                                          "optional_memory_budget_bytes": ctx.info(3), "optional_memory_in_use_bytes": ctx.info(4),
                                           "end_to_end_host_polynomial_ms": hdt * 1e3,
-                                          "note": "value: polynomial resident in device memory (halo_pcdl_open_dev); end_to_end: 32 MiB of "
-                                                  "coefficients copied from pageable host memory per open (halo_pcdl_open); median of %d samples "
-                                                  "(two sets of %d, before and after the host-path runs, pooled)" % (len(pooled), args.open_steps),
-                                          "samples_ms": [round(t * 1e3, 3) for t in ts_a + ts_b]}
+                                          "note": "value / ms: ONE open + check at a time, fold table in place (requested explicitly: halo_set_fold_table(ctx, 1); "
+                                                  "%s), polynomial resident in device memory (halo_pcdl_open_dev); without_fold_table_ms: the same with "
+                                                  "halo_set_fold_table(ctx, 0); end_to_end: 32 MiB of coefficients copied from pageable host memory per open "
+                                                  "(halo_pcdl_open); median of %d samples (two sets of %d, before and after the host-path runs, pooled)"
+                                                  % ("in place" if table_in_place else "NOT in place: budget or memory, the figure is the generic fold's", len(pooled), args.open_steps),
+                                          "samples_ms": [round(t * 1e3, 3) for t in ts_a + ts_b],
+                                          "samples_without_fold_table_ms": [round(t * 1e3, 3) for t in ts_plain]}
+            if args.concurrent_opens > 1:
+                # THROUGHPUT: independent open + check pairs in flight, each on its own context and host thread (contexts are
+                # independent by contract; ctypes releases the GIL).  An open alone leaves the GPU idle between its latency chains;
+                # two in flight fill each other's gaps.  Each context holds its own tables, so the budget for optional memory is
+                # raised explicitly for this leg and restored afterwards.
+                import threading
+                T = args.concurrent_opens
+                budget0 = ctx.info(3)
+                per_ctx = ctx.info(0) + ctx.info(1)
+                ctx.set_memory_budget(max(budget0, ctx.info(4) + (T - 1) * per_ctx + (8 << 30)))
+                extra = [h._lib.Context(urs_n=n, device=gpu) for _ in range(T - 1)]
+                for c_ in extra:
+                    c_.set_fold_table(1 if table_in_place else 0)
+                    assert one(c_).tolist() == pi0.tolist()
+                    one(c_)
+                ctxs = [ctx] + extra
+                J = max(args.open_steps, 4)
+                errs = []
+
+                def worker(c_):
+                    try:
+                        torch.cuda.set_device(gpu)
+                        for _ in range(J):
+                            p_ = one(c_)
+                        if p_.tolist() != pi0.tolist():
+                            errs.append("proof differs")
+                    except Exception as e:  # noqa: BLE001
+                        errs.append(repr(e))
+
+                best = None
+                for _ in range(2):
+                    ths = [threading.Thread(target=worker, args=(c_,)) for c_ in ctxs]
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for th in ths:
+                        th.start()
+                    for th in ths:
+                        th.join()
+                    dtc = time.perf_counter() - t0
+                    best = dtc if best is None else min(best, dtc)
+                assert not errs, errs
+                result["pcdl_open_check"]["in_flight"] = {"pairs_in_flight": T, "value": T * J / best, "unit": "open+check/s", "ms_per_pair": best / (T * J) * 1e3,
+                                                          "fold_tables_in_place": [c_.info(1) > 0 for c_ in ctxs],
+                                                          "optional_memory_budget_raised_to": ctx.info(3), "optional_memory_in_use_bytes": ctx.info(4),
+                                                          "note": "%d independent open + check pairs at a time, one context + host thread each, %d pairs per thread, "
+                                                                  "best of 2 runs; every proof equals the single-context proof" % (T, J)}
+                for c_ in extra:
+                    c_.close()
+                ctx.set_memory_budget(budget0)
+            if ctx_small is not None:
+                # the same at the CPU baseline's size (the reference's own D + 1, consts.rs:23): the GPU figure that stands beside it
+                ns = small_n
+                cs, zs = np.ascontiguousarray(co[:ns]), np.ascontiguousarray(co[n])
+                Cs = pcdl.commit(ctx_small, cs, ns - 1)
+                vs = ctx_small.poly_eval(cs, zs)
+                ps = pcdl.open(ctx_small, [1], cs, Cs, ns - 1, zs)
+                ots, cts_s = [], []
+                for _ in range(max(args.open_steps, 5)):
+                    t0 = time.perf_counter()
+                    ps2 = pcdl.open(ctx_small, [1], cs, Cs, ns - 1, zs)
+                    t1 = time.perf_counter()
+                    pcdl.check_proof(ctx_small, Cs, ns - 1, zs, vs, ps2)
+                    t2 = time.perf_counter()
+                    ots.append(t1 - t0); cts_s.append(t2 - t1)
+                assert ps2.tolist() == ps.tolist()
+                gpu_side["open_small"] = {"n": ns, "coeffs": cs, "z": zs, "C": Cs, "v": vs, "proof": ps, "open_ms": median(ots) * 1e3, "check_ms": median(cts_s) * 1e3}
+                gpu_side["open_full"] = {"C": C, "z": zw[0], "v": v, "proof": pi, "check_ms": median(cts) * 1e3, "open_ms": odt * 1e3 - median(cts) * 1e3}
         if args.fr_reps > 0:
             # The bandwidth-side Fr kernels, each alone: `fr_reps` back-to-back launches through the library's
             # measurement hook, HIP events around every launch (these include ~2-3 us of dispatch per launch; the rocprofv3
@@ -477,25 +630,140 @@ def main():
             # BASELINE configs[3], the shape of benches/acc.rs:64-98 on a short chain: K x (random_instance + prover), K x verifier,
             # one decider (tests/test_gpu_pcdl_acc.py runs the full 64-step chain)
             from halo_accumulation_amd import acc as A
-            d = n - 1
-            rng_a = [0x48414C4F00000004]
-            accs, qss, acc_ = [], [], None
+
+            def chain(c_, d_, steps, seed):
+                rng_a = [seed]
+                accs, qss, acc_ = [], [], None
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    q = A.random_instance(c_, rng_a, d_)
+                    qs = [q] if acc_ is None else [A.instance_from_accumulator(c_, acc_, d_), q]
+                    acc_ = A.prover(c_, rng_a, d_, qs)
+                    accs.append(acc_); qss.append(qs)
+                t_chain = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for a_, qs in zip(accs, qss):
+                    A.verifier(c_, d_, qs, a_)
+                t_ver = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                A.decider(c_, accs[-1])
+                return t_chain / steps, t_ver / steps, time.perf_counter() - t0, accs
+
+            t_c, t_v, t_d, _ = chain(ctx, n - 1, args.asdl_steps, 0x48414C4F00000004)
+            result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_c * 1e3,
+                                    "verifier_ms_each": t_v * 1e3, "decider_ms": t_d * 1e3, "all_accepted": True,
+                                    "fold_table_in_place": ctx.info(1) > 0}
+            if ctx_small is not None:
+                ks = max(2, min(args.asdl_steps, 2))
+                chain(ctx_small, small_n - 1, 1, 0x48414C4F00000004)  # warm-up: buffers, launch graphs
+                t_c, t_v, t_d, accs_s = chain(ctx_small, small_n - 1, ks, 0x48414C4F00000004)
+                gpu_side["asdl_small"] = {"n": small_n, "steps": ks, "accs": accs_s, "instance_plus_prover_ms_each": t_c * 1e3, "verifier_ms_each": t_v * 1e3,
+                                          "decider_ms": t_d * 1e3}
+        if args.cpu_msms > 0:
+            # ---- the CPU leg: the ONLY place that touches oracle/ (the single-thread restatement of the arkworks path the reference
+            # runs: "port"), compiled on this host with -march=native.  It is the checker of everything above and the reported baseline.
+            os.environ["ORC_NATIVE"] = "1"
+            import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
+            gs = ctx.read_bases()
+            sc_all = sc_host
+            assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
             t0 = time.perf_counter()
-            for _ in range(args.asdl_steps):
-                q = A.random_instance(ctx, rng_a, d)
-                qs = [q] if acc_ is None else [A.instance_from_accumulator(ctx, acc_, d), q]
-                acc_ = A.prover(ctx, rng_a, d, qs)
-                accs.append(acc_); qss.append(qs)
-            t_chain = time.perf_counter() - t0
+            for _ in range(args.cpu_msms):
+                want = orc.msm_affine(gs, sc_all)
+            cpu_dt = (time.perf_counter() - t0) / args.cpu_msms
+            assert out.tolist() == want.tolist(), "GPU MSM differs from the CPU restatement"
+            result["bit_exact_vs_cpu"] = True
+            # the same port on all the host cores this process may use: independent MSMs, one per thread (ctypes releases the
+            # GIL); a reported figure next to the single-thread one, which is how the reference runs
+            import threading
+            try:
+                T = len(os.sched_getaffinity(0))
+            except Exception:
+                T = os.cpu_count() or 1
+            T = max(1, min(T, 64))
+            box = [None] * T
+
+            def one_cpu(k):
+                box[k] = orc.msm_affine(gs, sc_all)
+
             t0 = time.perf_counter()
-            for a_, qs in zip(accs, qss):
-                A.verifier(ctx, d, qs, a_)
-            t_ver = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            A.decider(ctx, accs[-1])
-            t_dec = time.perf_counter() - t0
-            result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_chain / args.asdl_steps * 1e3,
-                                    "verifier_ms_each": t_ver / args.asdl_steps * 1e3, "decider_ms": t_dec * 1e3, "all_accepted": True}
+            ths = [threading.Thread(target=one_cpu, args=(k,)) for k in range(T)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            par_dt = time.perf_counter() - t0
+            assert all(b.tolist() == want.tolist() for b in box)
+            build = "oracle/halo_cpu.c, gcc %s" % orc.BUILD_FLAGS
+            result["cpu_baseline_all_cores"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port", "cpu_model": cpu_model,
+                                                "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
+            result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "build": build,
+                                      "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
+                                      "host_cpus": os.cpu_count()}
+            if "open_small" in gpu_side:
+                # pcdl::open + check (pcdl.rs:120-242,323-342) on one core at the reference's own size, the same polynomial the GPU just
+                # opened: proofs compared bit for bit; then pcdl::check at the FULL size on the GPU's full-size proof (one MSM of n
+                # points + the expansion of h).  A full-size CPU open is not run (minutes): stated as the extrapolation it is.
+                g = gpu_side["open_small"]
+                ns = g["n"]
+                pp_s = orc.make_pp(np.ascontiguousarray(gs[:ns]))
+                t0 = time.perf_counter()
+                p_cpu, _ = orc.pcdl_open(pp_s, 1, g["coeffs"], g["C"], ns - 1, g["z"])
+                t1 = time.perf_counter()
+                orc.pcdl_check(pp_s, g["C"], ns - 1, g["z"], g["v"], p_cpu)
+                t2 = time.perf_counter()
+                assert p_cpu.tolist() == g["proof"].tolist(), "GPU proof differs from the CPU restatement's"
+                cb = {"value": 1.0 / (t2 - t0), "unit": "open+check/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "build": build,
+                      "n": ns, "open_ms": (t1 - t0) * 1e3, "check_ms": (t2 - t1) * 1e3,
+                      "sample": "one pcdl::open + one pcdl::check at n=2^%d (consts.rs:23: the reference's D + 1), non-hiding, 1 thread" % (ns.bit_length() - 1),
+                      "gpu_same_n": {"open_ms": g["open_ms"], "check_ms": g["check_ms"], "value": 1e3 / (g["open_ms"] + g["check_ms"]), "unit": "open+check/s",
+                                     "note": "halo_pcdl_open + halo_pcdl_check at the same n, coefficients from host memory, one at a time"},
+                      "proof_bit_exact": True}
+                if "open_full" in gpu_side and n > ns:
+                    f = gpu_side["open_full"]
+                    pp_f = orc.make_pp(gs)
+                    t0 = time.perf_counter()
+                    orc.pcdl_check(pp_f, f["C"], n - 1, f["z"], f["v"], f["proof"])
+                    t_chk = time.perf_counter() - t0
+                    # open: every term of its cost is linear in n or n lg n (the folds: n scalar multiples in all; the 2 lg n MSMs: 2 n
+                    # points in all; p(z), h): scaled by n / n_small from the measured small open -- an EXTRAPOLATION, marked as one
+                    ext_open = cb["open_ms"] / 1e3 * (n / ns)
+                    cb["full_size"] = {"n": n, "check_ms": t_chk * 1e3, "check_sample": "one full pcdl::check at n=2^%d on the GPU's proof (accepted), 1 thread" % args.log_n,
+                                       "gpu_check_ms": f["check_ms"],
+                                       "open_ms_extrapolated": ext_open * 1e3, "open_extrapolation": "measured open at n=2^%d x %d (cost linear in n); NOT measured" % (ns.bit_length() - 1, n // ns),
+                                       "open_plus_check_per_s_extrapolated": 1.0 / (ext_open + t_chk), "gpu_open_ms": f["open_ms"]}
+                result["pcdl_open_check"]["cpu_baseline"] = cb
+            if "asdl_small" in gpu_side:
+                # benches/acc.rs:64-106 on one core at the same size: K x (random_instance + prover), K x verifier, one decider; the
+                # accumulators must equal the GPU's blob for blob (same SplitMix64 stream)
+                g = gpu_side["asdl_small"]
+                ns, ks = g["n"], g["steps"]
+                pp_s = orc.make_pp(np.ascontiguousarray(gs[:ns]))
+                lgs = ns.bit_length() - 1
+                seed, acc_, accs_c, qss = 0x48414C4F00000004, None, [], []
+                t0 = time.perf_counter()
+                for _ in range(ks):
+                    q, seed = orc.random_instance(pp_s, seed, ns - 1)
+                    qs = [q] if acc_ is None else [np.ascontiguousarray(acc_[: orc.instance_words(lgs)]).copy(), q]
+                    acc_, seed = orc.acc_prover(pp_s, seed, ns - 1, qs)
+                    accs_c.append(acc_); qss.append(qs)
+                t_chain = (time.perf_counter() - t0) / ks
+                t0 = time.perf_counter()
+                for a_, qs in zip(accs_c, qss):
+                    orc.acc_verifier(pp_s, ns - 1, qs, a_)
+                t_ver = (time.perf_counter() - t0) / ks
+                t0 = time.perf_counter()
+                orc.acc_decider(pp_s, accs_c[-1])
+                t_dec = time.perf_counter() - t0
+                assert all(a.tolist() == b.tolist() for a, b in zip(accs_c, g["accs"])), "GPU accumulators differ from the CPU restatement's"
+                result["asdl_chain"]["cpu_baseline"] = {
+                    "value": 1.0 / t_chain, "unit": "chain steps/s (random_instance + prover)", "cores": 1, "kind": "port", "cpu_model": cpu_model, "build": build, "n": ns,
+                    "instance_plus_prover_ms_each": t_chain * 1e3, "verifier_ms_each": t_ver * 1e3, "decider_ms": t_dec * 1e3,
+                    "sample": "%d chain steps at n=2^%d (benches/acc.rs:64-106 shape), then %d verifiers and one decider, 1 thread" % (ks, lgs, ks),
+                    "gpu_same_n": {"instance_plus_prover_ms_each": g["instance_plus_prover_ms_each"], "verifier_ms_each": g["verifier_ms_each"], "decider_ms": g["decider_ms"]},
+                    "accumulators_bit_exact": True}
+        if ctx_small is not None and ctx_small is not ctx:
+            ctx_small.close()
     if (world > 1 or force_dist) and args.open_steps > 0 and world & (world - 1) == 0 and n % world == 0:
         # BASELINE configs[2] on N GPUs: pcdl::open + check with the key, the coefficients and the z-powers placed cyclically
         # (element i on rank i mod N; sharded.ShardedOpen): per round one all-gather of 256 B per rank, no vector exchange;

@@ -129,6 +129,7 @@ _SIGS = {
     "halo_set_table_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_fold_table": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_ctx_info": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "halo_set_memory_budget": (C.c_int, [C.c_void_p, C.c_size_t]),
     "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
@@ -407,6 +408,10 @@ class Context:
     def info(self, what: int) -> int:
         """0: MSM table bytes, 1: fold table bytes, 2: fold table build time in microseconds"""
         return self.lib.halo_ctx_info(self.h, what)
+
+    def set_memory_budget(self, nbytes: int):
+        """budget for optional table memory on this context's device, process-wide (halo_set_memory_budget)"""
+        check(self.lib.halo_set_memory_budget(self.h, int(nbytes)))
 
     def set_table_mode(self, mode):
         check(self.lib.halo_set_table_mode(self.h, mode))

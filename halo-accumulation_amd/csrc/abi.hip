@@ -1174,6 +1174,8 @@ int halo_set_table_mode(halo_ctx *ctx, int mode) {
         if (rc) return rc;
     }
     ctx->table_mode = mode;
+    ctx->table_retry_at = 0;
+    ctx->table_status = 0;
     for (halo_ctx *sh : ctx->shards) (void)halo_set_table_mode(sh, mode);  // a multi-device context: its shards run the MSMs
     return HALO_OK;
 }
@@ -1201,14 +1203,88 @@ int halo_set_fold_table(halo_ctx *ctx, int mode) {
         foldtab_release(ctx);
     }
     ctx->fold_table_mode = mode;
+    ctx->foldtab_retry_at = 0;  // (a table that could not be had before is considered again)
+    ctx->foldtab_status = 0;
     return HALO_OK;
 }
-/* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds its build took */
+}  // extern "C"
+// ------------------------------------------------------------------ budget for optional device memory
+namespace halo {
+namespace {
+struct DeviceBudget { size_t budget = 0, used = 0; bool known = false; };
+std::mutex g_budget_mu;
+DeviceBudget g_budget[64];
+// HALO_MEMORY_BUDGET=<bytes>[K|M|G] in the environment replaces the default (for hosts that cannot call the setter: the Rust shim)
+size_t parse_bytes(const char *e) {
+    char *rest = nullptr;
+    double v = strtod(e, &rest);
+    if (rest && (*rest == 'K' || *rest == 'k')) v *= 1024.0;
+    else if (rest && (*rest == 'M' || *rest == 'm')) v *= 1024.0 * 1024.0;
+    else if (rest && (*rest == 'G' || *rest == 'g')) v *= 1024.0 * 1024.0 * 1024.0;
+    return v > 0 ? (size_t)v : 0;
+}
+DeviceBudget &budget_of(int device) {  // (g_budget_mu held; the device is current)
+    DeviceBudget &b = g_budget[device & 63];
+    if (!b.known) {
+        b.known = true;
+        size_t free_b = 0, total = 0;
+        if (const char *e = getenv("HALO_MEMORY_BUDGET")) b.budget = parse_bytes(e);
+        else if (hipMemGetInfo(&free_b, &total) == hipSuccess) b.budget = total / 6;  // 48 GB of an MI355X's 288
+        else (void)hipGetLastError();
+    }
+    return b;
+}
+}  // namespace
+bool table_budget_reserve(halo_ctx *ctx, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    DeviceBudget &b = budget_of(ctx->device);
+    size_t free_b = 0, total = 0;
+    if (hipMemGetInfo(&free_b, &total) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (b.used + bytes > b.budget || free_b / 2 < bytes) {
+        if (debug_trace()) fprintf(stderr, "[halo] optional table of %zu bytes refused on device %d: %zu of %zu budget bytes in use, %zu free\n", bytes, ctx->device, b.used, b.budget, free_b);
+        return false;
+    }
+    b.used += bytes;
+    ctx->budget_held += bytes;
+    return true;
+}
+void table_budget_release(halo_ctx *ctx, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    DeviceBudget &b = g_budget[ctx->device & 63];
+    if (bytes > ctx->budget_held) bytes = ctx->budget_held;
+    ctx->budget_held -= bytes;
+    b.used = b.used >= bytes ? b.used - bytes : 0;
+}
+}  // namespace halo
+extern "C" {
+int halo_set_memory_budget(halo_ctx *ctx, size_t bytes) {
+    HALO_CTX(ctx);
+    {
+        std::lock_guard<std::mutex> lk(g_budget_mu);
+        DeviceBudget &b = budget_of(ctx->device);
+        b.budget = bytes;
+    }
+    // a table that was refused is considered again at the next opportunity
+    ctx->foldtab_retry_at = 0; ctx->table_retry_at = 0;
+    for (halo_ctx *sh : ctx->shards) (void)halo_set_memory_budget(sh, bytes);  // (a shard on another device: that device's budget)
+    return HALO_OK;
+}
+/* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds its build took, 3 = the budget for optional
+ * table memory on this context's device, 4 = bytes of it in use (all contexts of the process), 5 / 6 = status of the fold table / the
+ * MSM table: 0 nothing yet, 1 memory requested, 2 built, 3 over the budget, 4 allocation failed (tried again later), 5 off */
 size_t halo_ctx_info(const halo_ctx *ctx, int what) {
     if (!ctx) return 0;
     if (what == 0) return ctx->d_table ? (size_t)ctx->tbl.W * ctx->n * 128 : 0;
     if (what == 1) return ctx->foldtab_bytes;
     if (what == 2) return (size_t)(ctx->foldtab_build_ms * 1e3);
+    if (what == 3 || what == 4) {
+        std::lock_guard<std::mutex> lk(g_budget_mu);
+        (void)hipSetDevice(ctx->device);
+        DeviceBudget &b = budget_of(ctx->device);
+        return what == 3 ? b.budget : b.used;
+    }
+    if (what == 5) return ctx->fold_table_mode == 0 ? 5 : ctx->d_foldtab ? 2 : (size_t)ctx->foldtab_status;
+    if (what == 6) return ctx->table_mode == 0 ? 5 : ctx->d_table ? 2 : (size_t)ctx->table_status;
     return 0;
 }
 int halo_set_task_len(halo_ctx *ctx, int len) {

@@ -12,9 +12,13 @@
 // coalesced 4 KiB read (2.1 GB per pass at n = 2^20).
 //
 // Cost: 35.4 GB at n = 2^20 (of 288 GB) and ~0.2 s to build (704 group operations and one share of an inversion per table
-// entry) -- seventy opens' worth of savings.  So the table is built on the SECOND full-size open of a context (mode -1,
-// default; halo_set_fold_table: 1 = at the first, 0 = never), which a prover chain (acc.rs:190-228: two opens per step)
-// reaches at once and a single open never does.  No memory, no table: the generic kernel gives the same points.
+// entry) -- seventy opens' worth of savings.  Mode -1 (default; halo_set_fold_table: 1 = allocated and built at the first
+// full-size open, 0 = never): the first full-size open of a context of 2^18 .. 2^21 points asks for the memory on a helper
+// thread (hipMalloc of 40 GB takes 0.5 ms .. 2 s) and takes the generic kernel; the first later open that finds the memory
+// there builds the table -- a prover chain (acc.rs:190-228: two opens per step) gets it at once, a single open never waits.
+// The memory is OPTIONAL memory: it is reserved against the device's budget (halo_set_memory_budget, default 1/6 of the
+// device) before it is requested, and never more than half of what is free is taken.  No budget, no memory, no table: the
+// generic kernel gives the same points, and the table is tried again later.
 #include "curve.hpp"
 #include "internal.hpp"
 
@@ -215,34 +219,59 @@ void fold_digits_host(const host::Fr &s, int8_t out[2 * FT_WINDOWS]) {
     signed_digits64(k2, out + FT_WINDOWS);
 }
 
+static size_t foldtab_slice(size_t cnt) { return cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15); }  // 32768 points x 704 entries x 200 B = 4.6 GB of temporaries
+static size_t foldtab_table_bytes(size_t n) { return (size_t)FT_ENTRIES * (n - n / 4) * FT_WORDS * 4; }
+static size_t foldtab_tmp_bytes(size_t n) { return (size_t)FT_ENTRIES * foldtab_slice(n - n / 4) * FT_TMP_WORDS * 4; }
+
 void foldtab_release(halo_ctx *ctx) {
     foldtab_cancel_alloc(ctx);
     if (!ctx->d_foldtab) return;
     alloc_epoch_bump(ctx);
     (void)hipFree(ctx->d_foldtab);
+    table_budget_release(ctx, ctx->foldtab_bytes);
     ctx->d_foldtab = nullptr;
     ctx->foldtab_bytes = 0;
+    ctx->foldtab_status = 0;
 }
 
 // the table over [n/4, n) of the context's key, built in slices through a temporary of at most ~4 GiB
-static size_t foldtab_slice(size_t cnt) { return cnt < ((size_t)1 << 15) ? cnt : ((size_t)1 << 15); }  // 32768 points x 704 entries x 200 B = 4.6 GB of temporaries
 static hipError_t foldtab_alloc(size_t n, uint32_t **tab, uint32_t **tmp) {
-    const size_t cnt = n - n / 4, bytes = (size_t)FT_ENTRIES * cnt * FT_WORDS * 4;
-    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(tab, bytes);
-    if (e == hipSuccess) e = hipMalloc(tmp, (size_t)FT_ENTRIES * foldtab_slice(cnt) * FT_TMP_WORDS * 4);
+    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(tab, foldtab_table_bytes(n));
+    if (e == hipSuccess) e = hipMalloc(tmp, foldtab_tmp_bytes(n));
     return e;
 }
+// The memory of table + temporary is RESERVED against the device's budget for optional memory before anything is allocated
+// (internal.hpp table_budget_reserve: all contexts of the process on this device together stay within it, and never more than
+// half of what is free at that moment is taken) and given back on every path that does not end with a table.
+static bool foldtab_reserve(halo_ctx *ctx) { return table_budget_reserve(ctx, foldtab_table_bytes(ctx->n) + foldtab_tmp_bytes(ctx->n)); }
+static void foldtab_unreserve(halo_ctx *ctx, bool keep_table) {
+    table_budget_release(ctx, foldtab_tmp_bytes(ctx->n) + (keep_table ? 0 : foldtab_table_bytes(ctx->n)));
+}
+// not now: tried again after foldtab_backoff more full-size opens (8, 16, ... 1024) -- memory comes back when other contexts
+// go, budgets are raised (no latch) -- and said once on stderr; halo_ctx_info(ctx, 5) carries the status
+static void foldtab_later(halo_ctx *ctx, int status, const char *why) {
+    ctx->foldtab_status = status;
+    ctx->foldtab_retry_at = ctx->foldtab_opens + ctx->foldtab_backoff;
+    if (ctx->foldtab_backoff < 1024) ctx->foldtab_backoff *= 2;
+    if (!ctx->foldtab_said)
+        fprintf(stderr, "[halo] fold table of %zu bytes not built (%s): the generic fold kernel runs, same proofs (halo_ctx_info 5; tried again later)\n",
+                foldtab_table_bytes(ctx->n), why);
+    ctx->foldtab_said = true;
+}
 void foldtab_cancel_alloc(halo_ctx *ctx) {
+    bool had = ctx->foldtab_alloc_state.load(std::memory_order_acquire) != 0;
     if (ctx->foldtab_alloc_thread.joinable()) ctx->foldtab_alloc_thread.join();
     if (ctx->foldtab_pending) (void)hipFree(ctx->foldtab_pending);
     if (ctx->foldtab_pending_tmp) (void)hipFree(ctx->foldtab_pending_tmp);
     ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
+    if (had) foldtab_unreserve(ctx, false);
     ctx->foldtab_alloc_state = 0;
+    if (ctx->foldtab_status == 1) ctx->foldtab_status = 0;
 }
-// tab / tmp: buffers the helper thread obtained, or null (allocate here)
+// tab / tmp: buffers the helper thread obtained, or null (allocate here).  The caller holds the reservation.
 static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp = nullptr) {
     const size_t N = ctx->n, lo = N / 4, cnt = N - lo;
-    const size_t bytes = (size_t)FT_ENTRIES * cnt * FT_WORDS * 4;
+    const size_t bytes = foldtab_table_bytes(N);
     auto t0 = std::chrono::steady_clock::now();
     size_t slice = foldtab_slice(cnt);
     hipError_t e = tab ? hipSuccess : foldtab_alloc(N, &tab, &tmp);
@@ -266,13 +295,15 @@ static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp =
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (tab) (void)hipFree(tab);
-        ctx->fold_table_mode = 0;  // this context carries on with the generic fold and does not try again
-        fprintf(stderr, "[halo] fold table of %zu bytes not built (%s): this context continues without it\n", bytes, hipGetErrorString(e));
+        foldtab_unreserve(ctx, false);
+        foldtab_later(ctx, 4, hipGetErrorString(e));  // this context carries on with the generic fold
         return HALO_OK;
     }
+    foldtab_unreserve(ctx, true);  // the temporary is gone, the table stays on the books
     alloc_epoch_bump(ctx);
     ctx->d_foldtab = tab;
     ctx->foldtab_bytes = bytes;
+    ctx->foldtab_status = 2;
     ctx->foldtab_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (debug_trace())
         fprintf(stderr, "[halo] fold table ctx=%p [%p, +%zu) built in %.1f ms (%.1f ms of it the two allocations)\n", (void *)ctx, (void *)tab, bytes,
@@ -285,27 +316,37 @@ static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp =
 int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]) {
     if (d_src != ctx->d_bases || 4 * m != ctx->n || m < 16 || d_dst == d_src || ctx->fold_table_mode == 0) return 0;
     if (!ctx->d_foldtab) {
-        // mode 1: at the first full-size open; default: at the second (a context that opens once never pays the build)
+        // mode 1: at the first full-size open; default (-1): the memory is requested on a helper thread at the first full-size
+        // open and the table is built at the first later open that finds it there (a context that opens once never waits)
         ctx->foldtab_opens++;
         // (automatic mode also stops at 2^21 points: 71 GB; larger keys on request only)
         int rc;
         if (ctx->fold_table_mode == 1) {
             // (a request of the automatic mode may still be under way: wait for it and take what it brought)
             uint32_t *tab = nullptr, *tmp = nullptr;
+            bool reserved = false;
             if (ctx->foldtab_alloc_state.load(std::memory_order_acquire) != 0) {
                 if (ctx->foldtab_alloc_thread.joinable()) ctx->foldtab_alloc_thread.join();
                 if (ctx->foldtab_alloc_state.load(std::memory_order_acquire) == 2) {
                     tab = ctx->foldtab_pending; tmp = ctx->foldtab_pending_tmp;
                     ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
                     ctx->foldtab_alloc_state = 0;
+                    reserved = true;  // (the request's reservation passes to the build)
                 } else foldtab_cancel_alloc(ctx);
+            }
+            if (!reserved) {
+                if (ctx->foldtab_opens < ctx->foldtab_retry_at) return 0;
+                if (!foldtab_reserve(ctx)) { foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
             }
             rc = foldtab_build(ctx, tab, tmp);
         } else {
             if (!(ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21))) return 0;
             int st = ctx->foldtab_alloc_state.load(std::memory_order_acquire);
             if (st == 0) {  // first full-size open: ask for the memory in the background; this open takes the generic kernel
+                if (ctx->foldtab_opens < ctx->foldtab_retry_at) return 0;
+                if (!foldtab_reserve(ctx)) { foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
                 ctx->foldtab_alloc_state = 1;
+                ctx->foldtab_status = 1;
                 ctx->foldtab_alloc_thread = std::thread([ctx] {
                     (void)hipSetDevice(ctx->device);
                     hipError_t e = foldtab_alloc(ctx->n, &ctx->foldtab_pending, &ctx->foldtab_pending_tmp);
@@ -317,9 +358,8 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
             if (st == 1) return 0;  // not there yet: the generic kernel once more
             ctx->foldtab_alloc_thread.join();
             if (st == 3) {
-                foldtab_cancel_alloc(ctx);
-                ctx->fold_table_mode = 0;
-                fprintf(stderr, "[halo] fold table: no memory: this context continues without it\n");
+                foldtab_cancel_alloc(ctx);  // (frees what the request got, gives the reservation back)
+                foldtab_later(ctx, 4, "no memory");
                 return 0;
             }
             uint32_t *tab = ctx->foldtab_pending, *tmp = ctx->foldtab_pending_tmp;

@@ -139,8 +139,9 @@ constexpr int HALO_SLOTS = 4;
 
 namespace halo {
 // One helper thread per context for pure host arithmetic that would otherwise serialise on the caller's thread
-// (the window combine of the second MSM of an IPA round while the caller combines the first).  It never touches
-// HIP.  While an IPA state of the context is alive (`hot` counts them) a round arrives every few hundred
+// (the window combine of the second MSM of an IPA round while the caller combines the first); a shard of a multi-device
+// context also runs its own HIP calls on it (multi.hip: copies, launches and the stream wait of its stretch of an MSM, on
+// its own device).  While an IPA state of the context is alive (`hot` counts them) a round arrives every few hundred
 // microseconds and a condition-variable wake-up would cost a good part of what the overlap saves, so after a job
 // the thread polls for the next one -- but only for SPIN_US: an idle state (a caller thinking between rounds, a long
 // sharded open waiting on a collective) does not hold a core; the thread falls back to the condition variable.
@@ -154,9 +155,20 @@ class HostWorker {
         { std::lock_guard<std::mutex> lk(mu_); pending_.store(true, std::memory_order_release); }
         cv_.notify_one();
     }
+    // A job of pure host arithmetic ends within tens of microseconds: poll for it.  A job that sits in hipStreamSynchronize
+    // for the length of an MSM (multi.hip: a shard's stretch) would make the caller burn a core per shard for milliseconds:
+    // after SPIN_US of polling the caller sleeps on a condition variable instead.
     void wait() {
         if (!thread_.joinable()) return;
-        while (!done_.load(std::memory_order_acquire)) std::this_thread::yield();
+        auto t0 = std::chrono::steady_clock::now();
+        while (!done_.load(std::memory_order_acquire)) {
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < SPIN_US) {
+                std::this_thread::yield();
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [this] { return done_.load(std::memory_order_acquire); });
+        }
     }
     // one call per IPA state created (+1) / destroyed (-1)
     void add_hot(int delta) {
@@ -193,13 +205,14 @@ class HostWorker {
             }
             pending_.store(false, std::memory_order_relaxed);
             job_();
-            done_.store(true, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(mu_); done_.store(true, std::memory_order_release); }  // (under the lock: a waiter about to sleep cannot miss it)
+            done_cv_.notify_all();
             last = std::chrono::steady_clock::now();
         }
     }
     std::thread thread_;
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, done_cv_;
     std::function<void()> job_;
     std::atomic<bool> pending_{false}, done_{true}, quit_{false};
     std::atomic<int> hot_{0};
@@ -222,7 +235,7 @@ struct halo_ctx {
     hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
     hipStream_t streams[HALO_SLOTS] = {};
     size_t n = 0;
-    uint32_t *d_bases = nullptr;  // n x 20 words: native affine (curve.hpp AffN)
+    uint32_t *d_bases = nullptr;  // n x 32 words (AFF_STRIDE): native affine x | y | -y, one 128-byte line per point (curve.hpp AffN)
     halo::MsmWorkspace wss[HALO_SLOTS];        // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     std::vector<halo::ProfEntry> prof_merged;  // what halo_prof_count / _get show: this context's entries plus its shards'
@@ -237,11 +250,19 @@ struct halo_ctx {
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 14;  // key size at which the IPA stops folding G (0/1 = never)
     bool batch_verify = true;              // succinct checks of >= 64 instances in two device launches (else a host thread pool)
-    int fold_table_mode = -1;              // comb table for the first fold of an open (foldtab.hip): -1 from the second full-size open on, 1 at once, 0 never
-    uint32_t *d_foldtab = nullptr;         // E[w][d][i - n/4] = d 16^w G_i, 64-byte affine entries
+    int fold_table_mode = -1;              // comb table for the first fold of an open (foldtab.hip): -1 memory requested at the first full-size open, built at the first later one that finds it; 1 at once; 0 never
+    uint32_t *d_foldtab = nullptr;         // E[w][d][i - n/4] = d 64^w G_i, 64-byte affine entries
     size_t foldtab_bytes = 0;
     double foldtab_build_ms = 0;
     int foldtab_opens = 0;                 // full-size opens seen while the table did not exist
+    // A table that could not be had (budget, allocation) is tried again later, with a doubling back-off, instead of never:
+    // memory comes back when other contexts go.  status: 0 nothing yet, 1 memory requested, 2 built, 3 over the
+    // memory budget, 4 allocation or build failed, 5 off (halo_ctx_info 5 / 6)
+    int foldtab_retry_at = 0, foldtab_backoff = 8, foldtab_status = 0;
+    long table_calls = 0, table_retry_at = 0, table_backoff = 64;
+    int table_status = 0;
+    bool table_said = false, foldtab_said = false;  // the one line on stderr has been printed
+    size_t budget_held = 0;                // optional table memory this context holds against its device's budget (abi.hip)
     // automatic mode: the table's 40 GB are requested on a helper thread at the first full-size open (hipMalloc of that size
     // takes 0.5 ms .. 2 s depending on what the driver has at hand) and the table is built at the first later open that
     // finds them there.  state: 0 nothing, 1 running, 2 ready, 3 failed
@@ -261,7 +282,7 @@ struct halo_ctx {
     size_t verify_words = 0;
     // lazily allocated n x 4 polynomial buffers for pcdl::open / acc::prover
     uint64_t *d_poly = nullptr, *d_poly2 = nullptr;
-    halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker)
+    halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker; multi.hip also runs a shard's HIP calls on it)
     IpaBuffers ipa_bufs;          // reused by every halo_ipa of this context (one at a time; a second one allocates its own)
     uint64_t alloc_epoch = 0;     // bumped whenever this context allocates or frees device memory (see msm.hip, launch graphs)
     // multi-device contexts (multi.hip): one shard context per device over its index block of the key; MSMs over the key fan out
@@ -337,6 +358,12 @@ int aff_words_to_native(halo_ctx *ctx, const uint64_t *d_in, size_t n, uint32_t 
 int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *d_out);
 int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+
+// ---- abi.hip: the budget for OPTIONAL device memory (the MSM fixed-base table, the fold table and its temporary), per device and
+// process-wide: reserve() succeeds if what all contexts of this process hold on ctx's device plus `bytes` stays within the
+// device's budget (halo_set_memory_budget; default 1/6 of the device's memory) and at least 2 x bytes are free right now
+bool table_budget_reserve(halo_ctx *ctx, size_t bytes);
+void table_budget_release(halo_ctx *ctx, size_t bytes);
 
 // ---- foldtab.hip: the first two-level fold of an open from a comb table over the context's key
 void foldtab_cancel_alloc(halo_ctx *ctx);  // joins the helper thread and frees what it obtained

@@ -378,7 +378,16 @@ HALO_DEV Fs<4> window_power(const uint64_t *__restrict__ tab, uint32_t e, int nw
 // waves on the chip; measured at n = 2^20 (tools/fr_kernels.py with HALO_POW_E = 2 .. 32): k_powers 8, k_poly_eval_partial
 // 16, k_h_coeffs 4 (its "seed" is one product per four elements whatever the length)
 static int pow_chain_len(size_t n, int best) {
-    static const int forced = getenv("HALO_POW_E") ? atoi(getenv("HALO_POW_E")) : 0;  // development override
+    // development override: a power of two in [4, 64] or it is ignored -- k_h_coeffs relies on a chain length that is a power of
+    // two (its mid * high factor is wave-uniform and changes every fourth step): another value would give wrong coefficients
+    static const int forced = [] {
+        int v = getenv("HALO_POW_E") ? atoi(getenv("HALO_POW_E")) : 0;
+        if (v != 0 && (v < 4 || v > 64 || (v & (v - 1)) != 0)) {
+            fprintf(stderr, "[halo] HALO_POW_E=%d ignored: the chain length must be a power of two in [4, 64]\n", v);
+            v = 0;
+        }
+        return v;
+    }();
     if (forced > 0) return forced;
     int e = best;
     while (e > 4 && n / (64 * (size_t)e) < 1024) e >>= 1;  // small inputs: at least a wave per SIMD

@@ -1450,21 +1450,22 @@ int aff_native_to_words(halo_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t 
 
 // ------------------------------------------------------------------------------ URS
 static const std::vector<uint64_t> &urs_table() {
-    static std::vector<uint64_t> tbl;
-    if (tbl.empty()) {
-        tbl.assign(64 * 16 * 8, 0);
+    // (a function-local static initialised by a lambda: thread-safe, two threads may create their first contexts at once)
+    static const std::vector<uint64_t> tbl = [] {
+        std::vector<uint64_t> t(64 * 16 * 8, 0);
         host::Point base = host::Point::generator();
         for (int w = 0; w < 64; ++w) {
             host::Point acc = host::Point::infinity();
             for (int d = 1; d < 16; ++d) {
                 acc = acc + base;
                 host::Affine a = acc.to_affine();
-                a.x.store(&tbl[(size_t)(w * 16 + d) * 8]);
-                a.y.store(&tbl[(size_t)(w * 16 + d) * 8 + 4]);
+                a.x.store(&t[(size_t)(w * 16 + d) * 8]);
+                a.y.store(&t[(size_t)(w * 16 + d) * 8 + 4]);
             }
             base = base.dbl().dbl().dbl().dbl();
         }
-    }
+        return t;
+    }();
     return tbl;
 }
 
@@ -1582,6 +1583,7 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
 }
 void msm_workspace_free(halo_ctx *ctx) {
     alloc_epoch_bump(ctx);
+    if (ctx->d_table) table_budget_release(ctx, (size_t)ctx->tbl.W * ctx->n * 128);
     (void)hipFree(ctx->d_table);
     ctx->d_table = nullptr;
     for (int slot = 0; slot < HALO_SLOTS; ++slot) workspace_release(ctx->wss[slot]);
@@ -1739,15 +1741,28 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
 // of c doublings and an inversion per point, ~10 ms at n = 2^20)
 static int table_build(halo_ctx *ctx) {
     if (ctx->d_table) return HALO_OK;
+    // a table that could not be had is tried again after table_backoff more eligible MSMs (64, 128, ... 4096), not never:
+    // the memory may have come back, the budget may have been raised
+    if (++ctx->table_calls < ctx->table_retry_at) return HALO_OK;
     size_t n = ctx->n;
     TblPlan tp = table_plan(n);
+    const size_t bytes = (size_t)tp.W * n * 128;
+    auto later = [ctx, bytes](int status, const char *why) {
+        ctx->table_status = status;
+        ctx->table_retry_at = ctx->table_calls + ctx->table_backoff;
+        if (ctx->table_backoff < 4096) ctx->table_backoff *= 2;
+        if (!ctx->table_said)
+            fprintf(stderr, "[halo] fixed-base table of %zu bytes not built (%s): the table-free pipeline runs, same results (halo_ctx_info 6; tried again later)\n", bytes, why);
+        ctx->table_said = true;
+    };
+    if (!table_budget_reserve(ctx, bytes)) { later(3, "over the budget for optional memory, halo_set_memory_budget"); return HALO_OK; }
     alloc_epoch_bump(ctx);
     // built into a local pointer and published (d_table + tbl together) only after the last step has succeeded: a
     // half-built table is never visible to table_eligible / tmsm_enqueue_piece
     uint32_t *tbl = nullptr;
-    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tbl, (size_t)tp.W * n * 128);  // (test hook: the failure path)
+    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tbl, bytes);  // (test hook: the failure path)
     if (e == hipSuccess) {
-        if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)tbl, (size_t)tp.W * n * 128);
+        if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)tbl, bytes);
         e = hipMemcpyAsync(tbl, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream);
         for (int w = 1; w < tp.W && e == hipSuccess; ++w) {
             HALO_LAUNCH(ctx, "k_table_step", k_table_step, dim3((unsigned)(((n + TBL_E - 1) / TBL_E + 255) / 256)), dim3(256), 0,
@@ -1758,17 +1773,16 @@ static int table_build(halo_ctx *ctx) {
         if (e == hipSuccess) e = e2;
     }
     if (e != hipSuccess) {
-        // No table, no problem: the general pipeline needs no table memory and gives the same point.  The context stops
-        // trying (every later eligible MSM would fail the same way) and says so once.
+        // No table, no problem: the general pipeline needs no table memory and gives the same point.
         (void)hipGetLastError();
         if (tbl) (void)hipFree(tbl);
-        ctx->table_mode = 0;
-        fprintf(stderr, "[halo] fixed-base table of %zu bytes not built (%s): this context continues without tables\n", (size_t)tp.W * n * 128,
-                hipGetErrorString(e));
+        table_budget_release(ctx, bytes);
+        later(4, hipGetErrorString(e));
         return HALO_OK;
     }
     ctx->tbl = tp;
     ctx->d_table = tbl;
+    ctx->table_status = 2;
     return HALO_OK;
 }
 // halo_set_table_mode(ctx, 0): the table's memory goes back to the device (its launches have drained: every slot is idle)
@@ -1780,6 +1794,7 @@ int table_release(halo_ctx *ctx) {
     }
     alloc_epoch_bump(ctx);  // cached launch graphs name the table
     (void)hipFree(ctx->d_table);
+    table_budget_release(ctx, (size_t)ctx->tbl.W * ctx->n * 128);
     ctx->d_table = nullptr;
     ctx->tbl = TblPlan{};
     return HALO_OK;

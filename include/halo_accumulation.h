@@ -82,8 +82,9 @@ int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
 /* Asynchronous halves of halo_msm (scalars in HOST memory): begin() copies the scalars to the device on the slot's own
  * stream and enqueues the launch sequence behind the copy, end() waits and combines.  With two or more slots a caller
- * overlaps the copy of the next MSM (32 MiB at n = 2^20: PCIe time) with the kernels of the current one.  The scalars may be
- * reused as soon as begin() returns if they live in pageable memory; pinned memory must stay untouched until end(). */
+ * overlaps the copy of the next MSM (32 MiB at n = 2^20: PCIe time) with the kernels of the current one.  The scalars must
+ * stay untouched until end() returns, whatever memory they live in: begin() only ENQUEUES the copy (hipMemcpyAsync from
+ * the caller's pointer; the runtime may pin a pageable range in place and DMA from it later rather than stage it). */
 int halo_msm_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont);
 int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out_jac[12]);
 /* same, scalars already in device memory (n x 4 limbs, 32-byte aligned device pointer) */
@@ -308,14 +309,30 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
  * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */
 int halo_set_fold_levels(halo_ctx *ctx, int levels);
 /* IPA tuning: comb table for the first fold of an open whose size is the context's key (E[w][d][i] = d 64^w G_i: 22
- * windows x 32 multiples x 64 bytes per point of the upper three quarters of the key = 33 KiB x n: 35.4 GB at n = 2^20; ~0.2 s to
- * build; the scalars are split with the curve's endomorphism, 2 x 22 entries per scalar multiple).  -1 (default), contexts of 2^18 .. 2^21 points: the first full-size open asks for the
- * table's memory on a helper thread (40 GB at 2^20: 0.5 ms .. 2 s of hipMalloc depending on what the driver has at hand) and the
- * first later open that finds it there builds the table -- a prover chain (acc.rs:190-228) opens twice per step, a single open
- * never waits; 1: allocated and built at the first open; 0: never, a table already built (or requested) is released.
- * Results are identical; if the memory is not there the generic fold kernel runs. */
+ * windows x 32 multiples x 64 bytes per point of the upper three quarters of the key = 33 KiB x n: 35.4 GB at n = 2^20, plus a
+ * 4.6 GB temporary while it is built; ~0.2 s to build; the scalars are split with the curve's endomorphism, 2 x 22 entries per
+ * scalar multiple; an open + check at 2^20 takes ~3 ms less with it).  -1 (default), contexts of 2^18 .. 2^21 points: the first
+ * full-size open asks for the table's memory on a helper thread (40 GB at 2^20: 0.5 ms .. 2 s of hipMalloc depending on what
+ * the driver has at hand) and the first later open that finds it there builds the table -- a prover chain (acc.rs:190-228)
+ * opens twice per step, a single open never waits; 1: allocated and built at the first open; 0: never, a table already built
+ * (or requested) is released.  The table is OPTIONAL memory and subject to halo_set_memory_budget below: over the budget the
+ * generic fold kernel runs (halo_ctx_info(ctx, 5) says so) and the table is considered again later.  Results are identical. */
 int halo_set_fold_table(halo_ctx *ctx, int mode);
-/* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds the fold table took to build */
+/* Budget for OPTIONAL device memory -- the MSM fixed-base table (halo_set_table_mode) and the fold table above: memory the
+ * library takes on its own to be faster, never to be correct.  The budget is per DEVICE and process-wide: all contexts of
+ * this process on ctx's device together never hold more optional memory than `bytes`, and no single request takes more than
+ * half of what hipMemGetInfo reports free at that moment.  Default: one sixth of the device's total memory (48 GB of an
+ * MI355X's 288 GB: room for the tables of ONE context over 2^20 points, 37.1 GB + the 4.6 GB temporary -- a second context
+ * on the same device then runs without a fold table unless the caller raises the budget); environment
+ * HALO_MEMORY_BUDGET=<bytes>[K|M|G] replaces the default for the whole process.  0 = no optional memory at all.  Lowering
+ * the budget below what is held releases nothing by itself (halo_set_table_mode(ctx, 0) / halo_set_fold_table(ctx, 0) do).
+ * A table that was refused or whose allocation failed is tried again later (after 8, 16, ... more opens / 64, 128, ... more
+ * MSMs) and at once after this call. */
+int halo_set_memory_budget(halo_ctx *ctx, size_t bytes);
+/* what: 0 = bytes of the MSM fixed-base table, 1 = bytes of the fold table, 2 = microseconds the fold table took to build,
+ * 3 = the budget for optional memory on this context's device, 4 = bytes of it in use (all contexts of this process on
+ * that device), 5 = status of the fold table, 6 = status of the MSM table: 0 nothing yet, 1 memory requested, 2 built,
+ * 3 over the budget, 4 allocation failed (tried again later), 5 switched off */
 size_t halo_ctx_info(const halo_ctx *ctx, int what);
 /* verifier tuning: 1 (default) = succinct checks of >= 64 instances on the device, 0 = always the host thread pool */
 int halo_set_batch_verify(halo_ctx *ctx, int on);
@@ -330,7 +347,9 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode);
  * T[w][i] = 2^(20 w) G_i (13 x 128 bytes per point of the key, built on the first such MSM): 13 instead of 16 mixed
  * additions per point and one shared set of 2^19 buckets.  A context whose key has 2^17 .. 2^20 - 1 points builds
  * T[w][i] = 2^(17 w) G_i instead (15 x 128 bytes per point, 15 additions, 2^16 buckets) for MSMs over at least half of
- * its key.  0: never (no table memory).  Results are identical. */
+ * its key.  0: never (no table memory).  Optional memory: subject to halo_set_memory_budget; a table that cannot be had
+ * (budget, allocation) is not an error -- the table-free pipeline runs (halo_ctx_info(ctx, 6)) and the table is tried again
+ * later.  Results are identical. */
 int halo_set_table_mode(halo_ctx *ctx, int mode);
 /* MSM tuning: the 4-launch pipeline for MSMs of up to 2^16 points (sort per window in LDS, quad-parallel window sums):
  * -1 automatic (default), 0 never (the general pipeline at every size).  Results are identical. */

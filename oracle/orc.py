@@ -12,13 +12,38 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "liborc.so")
+# ORC_NATIVE=1 (bench.py's cpu_baseline leg sets it before importing this module): the library compiled with -march=native on
+# the host it runs on; falls back to the portable build (and says so in BUILD_FLAGS) if that compile is not possible
+NATIVE = os.environ.get("ORC_NATIVE") == "1"
+LIB_PATH = os.path.join(HERE, "_build", "liborc_native.so" if NATIVE else "liborc.so")
+BUILD_FLAGS = "-O3 -march=native" if NATIVE else "-O3 -march=x86-64-v2"
 
 
 def build(force: bool = False) -> str:
+    global LIB_PATH, BUILD_FLAGS
     src = os.path.join(HERE, "halo_cpu.c")
+    stamp = os.path.join(HERE, "_build", "native.host")
+    host = ""
+    if NATIVE:  # a native binary belongs to the CPU it was built on: rebuilt when the host's CPU model differs from the stamp
+        try:
+            host = [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0].strip()
+        except (OSError, IndexError):
+            host = "unknown"
+        force = force or not os.path.exists(stamp) or open(stamp).read() != host
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", HERE, "-s"])
+        try:
+            if NATIVE and os.path.exists(LIB_PATH):
+                os.remove(LIB_PATH)
+            subprocess.check_call(["make", "-C", HERE, "-s"] + (["native"] if NATIVE else []))
+            if NATIVE:
+                with open(stamp, "w") as f:
+                    f.write(host)
+        except (subprocess.CalledProcessError, OSError):
+            if not NATIVE:
+                raise
+            LIB_PATH, BUILD_FLAGS = os.path.join(HERE, "_build", "liborc.so"), "-O3 -march=x86-64-v2 (native build failed on this host)"
+            if not os.path.exists(LIB_PATH):
+                subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB_PATH
 
 

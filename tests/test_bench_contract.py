@@ -35,6 +35,22 @@ def test_bench_emits_contract_json():
     assert r["bit_exact_vs_cpu"] is True
     assert r["pcdl_open_check"]["value"] > 0 and r["pcdl_open_check"]["end_to_end_host_polynomial_ms"] > 0
     assert "fold_table_bytes" in r["pcdl_open_check"]
+    # the second half of the metric carries its own roofline and CPU baseline, the MSM a variable-base block
+    oc = r["pcdl_open_check"]
+    for k in ("without_fold_table_ms", "first_open_of_the_context_ms", "fold_table_in_place", "check_alone_ms", "roofline", "cpu_baseline"):
+        assert k in oc, k
+    assert oc["without_fold_table_ms"] > 0 and oc["roofline"]["kernel"].startswith("k_fold_points") and oc["roofline"]["achieved"] > 0
+    assert abs(oc["roofline"]["frac"] - oc["roofline"]["achieved"] / 8000.0) < 1e-12 and "traffic" in oc["roofline"]
+    ocb = oc["cpu_baseline"]
+    assert ocb["kind"] == "port" and ocb["cores"] == 1 and ocb["value"] > 0 and ocb["proof_bit_exact"] is True and ocb["gpu_same_n"]["value"] > 0
+    assert ocb["unit"] == "open+check/s" and "sample" in ocb and "-march=native" in ocb["build"]
+    assert oc["in_flight"]["pairs_in_flight"] == 2 and oc["in_flight"]["value"] > 0
+    acb = r["asdl_chain"]["cpu_baseline"]
+    assert acb["kind"] == "port" and acb["cores"] == 1 and acb["value"] > 0 and acb["accumulators_bit_exact"] is True
+    assert acb["gpu_same_n"]["instance_plus_prover_ms_each"] > 0 and acb["decider_ms"] > 0
+    vb = r["variable_base"]
+    assert vb["value"] > 0 and vb["roofline"]["kernel"] == "k_msm_accumulate" or vb["roofline"]["kernel_ms"] == 0  # (2^14: the small pipeline has no k_msm_accumulate)
+    assert abs(vb["roofline"]["frac"] - vb["roofline"]["achieved"] / 8000.0) < 1e-12 and "traffic" in vb["roofline"]
     assert r["timed_region"]["repetitions"] >= 1 and r["timed_region"]["reported"] == "median"
     assert r["end_to_end_host_scalars"]["value"] > 0 and r["asdl_chain"]["all_accepted"] is True
     assert "cpu_model" in cb and r["cpu_baseline_all_cores"]["cores"] >= 1
@@ -83,6 +99,27 @@ def test_bench_collective_path_over_rccl_with_one_rank():
     assert r["config"]["collective_backend"] == "nccl" and r["value"] > 0
     oc = r["pcdl_open_check_collective_path"]
     assert oc["ranks"] == 1 and oc["proof_equals_single_gpu"] is True and oc["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--devices", "0,0"], []])
+def test_bench_gpus_2_runs_without_a_launcher(extra):
+    """`python bench.py --gpus N` started plainly (no torch.distributed.run, WORLD_SIZE unset) must not die on
+    an assert: it takes the one-process path (multi-device context over devices 0..N-1) and says so; with one GPU on the box
+    the device ids repeat and the line says REHEARSAL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HALO_BENCH_BACKEND", "HALO_BENCH_FORCE_DIST")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "17", "--steps", "8", "--warmup", "2",
+                          "--min-seconds", "0"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["sharded_equals_single_gpu"] is True
+    sh = r["config"]["sharding"]
+    assert "one process, multi-device context" in sh and "started without a launcher" in sh
+    import torch
+    if torch.cuda.device_count() < 2 or extra:
+        assert "REHEARSAL" in sh and r["config"]["distinct_gpus"] == 1
 
 
 def test_bench_does_not_touch_the_oracle_outside_the_cpu_leg():

@@ -869,6 +869,63 @@ def test_fold_table_automatic_mode_allocates_in_the_background(hal):
         c2.close()
 
 
+def test_memory_budget_bounds_the_optional_tables_of_all_contexts_on_a_device(hal):
+    """VERDICT r3 #6 / ADVICE r3: the fold table and the MSM table are OPTIONAL memory under a per-device, process-wide budget
+    (halo_set_memory_budget; default 1/6 of the device).  Two contexts on the one GPU with room for ONE fold table: the first
+    gets it, the second runs the generic fold (status 3 = over the budget, same proof) and never pushes the device's total past
+    the budget; raising the budget lets it build at the next open; releasing gives the bytes back; budget 0 = no tables."""
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 18
+    d = n - 1
+    ft = 704 * 64 * (n - n // 4)           # 33 KiB per point of the upper three quarters of the key
+    tmp = 704 * 32768 * 200                 # the build's temporary
+    msm_tab = 15 * 128 * n                  # small-key MSM table (built by the commit)
+    a, b = hal._lib.Context(urs_n=n), hal._lib.Context(urs_n=n)
+    orig = a.info(3)
+    total = torch.cuda.mem_get_info()[1]
+    assert orig == total // 6 or os.environ.get("HALO_MEMORY_BUDGET"), "default: one sixth of the device's memory"
+    try:
+        used0 = a.info(4)  # what other live contexts of this process hold
+        dv = torch.empty((n + 1) * 4, dtype=torch.int64, device="cuda")
+        a.rng_scalars_dev(0xB0D6E7, n + 1, dv.data_ptr())
+        z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
+        budget = used0 + ft + tmp + 2 * msm_tab + (1 << 20)
+        a.set_memory_budget(budget)
+        assert b.info(3) == budget, "the budget belongs to the device, not to one context"
+        a.set_fold_table(1); b.set_fold_table(1)
+        Ca = pcdl.commit_dev(a, dv.data_ptr(), n, d)
+        pa = pcdl.open_dev(a, [1], dv.data_ptr(), n, Ca, d, z)
+        assert a.info(1) == ft and a.info(5) == 2 and a.info(0) == msm_tab and a.info(6) == 2
+        assert a.info(4) == used0 + ft + msm_tab, "the temporary is off the books again"
+        Cb = pcdl.commit_dev(b, dv.data_ptr(), n, d)
+        assert Cb.tolist() == Ca.tolist() and b.info(0) == msm_tab
+        pb = pcdl.open_dev(b, [1], dv.data_ptr(), n, Cb, d, z)
+        assert pb.tolist() == pa.tolist(), "the generic fold gives the same proof"
+        assert b.info(1) == 0 and b.info(5) == 3, "second fold table: over the budget"
+        assert a.info(4) == used0 + ft + 2 * msm_tab <= budget
+        for _ in range(3):  # refused: not asked again at every open (back-off), still the same proof
+            assert pcdl.open_dev(b, [1], dv.data_ptr(), n, Cb, d, z).tolist() == pa.tolist() and b.info(1) == 0
+        b.set_memory_budget(budget + ft)  # room for the second table: considered again at once
+        assert pcdl.open_dev(b, [1], dv.data_ptr(), n, Cb, d, z).tolist() == pa.tolist()
+        assert b.info(1) == ft and b.info(5) == 2 and b.info(4) == used0 + 2 * ft + 2 * msm_tab <= b.info(3)
+        a.set_fold_table(0)
+        assert a.info(1) == 0 and a.info(5) == 5 and a.info(4) == used0 + ft + 2 * msm_tab
+        a.set_table_mode(0)
+        assert a.info(0) == 0 and a.info(4) == used0 + ft + msm_tab
+        b.close()
+        assert a.info(4) == used0, "a destroyed context gives everything back"
+        # budget 0: no optional memory at all -- the table-free MSM pipeline, same point
+        a.set_memory_budget(0)
+        a.set_table_mode(-1)
+        assert pcdl.commit_dev(a, dv.data_ptr(), n, d).tolist() == Ca.tolist() and a.info(0) == 0 and a.info(6) == 3
+        assert a.info(4) == used0
+    finally:
+        a.set_memory_budget(orig)
+        a.close()
+        b.close()
+
+
 def test_sharded_entry_points_report_misuse_and_a_failing_collective(hal):
     """halo_pcdl_open_sharded / _check_sharded: a stride that is no power of two, an offset past it, ranks without an
     all-gather, and a collective that fails (a Python exception inside the callback must surface, not unwind the C frame)."""

@@ -12,6 +12,7 @@ if len(sys.argv) > 4:
     ctx.set_window_bits(int(sys.argv[4]))
 if len(sys.argv) > 5:
     ctx.set_reduce_span(int(sys.argv[5]))
+if os.environ.get("TABLE_MODE"): ctx.set_table_mode(int(os.environ["TABLE_MODE"]))  # 0: the general (variable-base) pipeline
 if os.environ.get("TASK_LEN"): ctx.set_task_len(int(os.environ["TASK_LEN"]))  # development sweep
 parts = int(os.environ.get("PARTS", "1"))
 d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
