@@ -495,9 +495,12 @@ def main():
             # Roofline of the open's dominant kernel = its longest single launch: the first two-level fold of G (pcdl.rs:216-219 applied
             # twice, n -> n / 4 points).  ALGORITHMIC bytes of that fold: n points of 64 B read, n / 4 written = 80 n.
             dom_o = max(((ms / max(cnt, 1), k) for k, (ms, cnt) in oprof.items() if k.startswith("k_fold_points")), default=(0.0, None))
+            is_fold = dom_o[1] is not None
+            if not is_fold:  # (sizes at which the key is never folded, n <= 2^14: the longest launch is a round's bucket kernel -- 96 B per point)
+                dom_o = max(((ms / max(cnt, 1), k) for k, (ms, cnt) in oprof.items()), default=(0.0, None))
             o_roof = None
             if dom_o[1]:
-                o_ms, o_alg = dom_o[0], 80 * n
+                o_ms, o_alg = dom_o[0], (80 * n if is_fold else 96 * n)
                 o_traffic, o_src = None, None
                 pmc = os.path.join(ROOT, "profiles", "r04_pmc_open_loop.json")
                 if args.log_n == 20 and table_in_place and os.path.exists(pmc):
