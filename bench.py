@@ -665,8 +665,8 @@ def main():
         if args.cpu_msms > 0:
             # ---- the CPU leg: the ONLY place that touches oracle/ (the single-thread restatement of the arkworks path the reference
             # runs: "port"), compiled on this host with -march=native.  It is the checker of everything above and the reported baseline.
-            os.environ["ORC_NATIVE"] = "1"
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
+            build_timings = orc.select_fastest()  # portable and -march=native builds timed on this host, the faster one kept
             gs = ctx.read_bases()
             sc_all = sc_host
             assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
@@ -697,7 +697,8 @@ def main():
                 th.join()
             par_dt = time.perf_counter() - t0
             assert all(b.tolist() == want.tolist() for b in box)
-            build = "oracle/halo_cpu.c, gcc %s" % orc.BUILD_FLAGS
+            build = "oracle/halo_cpu.c, gcc %s (the faster of the builds timed on this host: %s)" % (
+                orc.BUILD_FLAGS, ", ".join("%s %.1f ms per 2^13-point MSM" % (k, v * 1e3) for k, v in sorted(build_timings.items())))
             result["cpu_baseline_all_cores"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port", "cpu_model": cpu_model,
                                                 "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
             result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "build": build,

@@ -719,6 +719,11 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         return rcl;
     };
     if (dots_first) { int rcl = launch_dots(); if (rcl) return rcl; }
+    // the last round of a no-fold phase: its two coefficients travel to the host with the round's results (halo_ipa_finish
+    // gets U from this round's own MSMs; pinned words 208..215, read after the wait for stream 0 below)
+    const bool last_round = st->nofold && st->M > 1 && st->m == 2;
+    st->last_valid = false;
+    if (last_round) HALO_HIP(hipMemcpyAsync(ctx->h_pinned + 208, st->d_c, 64, hipMemcpyDeviceToHost, ctx->streams[0]));
     if (st->nofold) {
         rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
         if (rc) return rc;
@@ -758,10 +763,11 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     host::Point hterm[2] = {host::Point::infinity(), host::Point::infinity()};
     if (with_hterm && !rcd)
         for (int k = 0; k < 2; ++k) hterm[k] = st->hp_from_scalar ? public_h_table().mul(dots[k] * st->hp_scalar) : st->hp_table.mul(dots[k]);
-    auto finish_one = [ctx, with_hterm, &hterm, batched](int which, host::Point *out) {
+    auto finish_one = [ctx, st, last_round, with_hterm, &hterm, batched](int which, host::Point *out) {
         host::Point p;
         if (batched) msm_combine_member(ctx, 0, which, &p);
         else msm_combine(ctx, which, &p, 1);
+        if (last_round) (which == 0 ? st->last_L : st->last_R) = p;  // before the H' term
         if (with_hterm) p = (p + hterm[which]).normalized();
         *out = p;
     };
@@ -778,6 +784,12 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         g_rt.enqueue += t1 - t0; g_rt.dots += t2 - t1; g_rt.hterm += t3 - t2; g_rt.wait += t4 - t3; g_rt.combine += t5 - t4; g_rt.rounds++;
     }
     if (rc || rc2 || rcd) return rc ? rc : (rc2 ? rc2 : rcd);
+    if (last_round) {
+        st->last_c0 = host::Fr::load(ctx->h_pinned + 208);
+        st->last_c1 = host::Fr::load(ctx->h_pinned + 212);
+        st->last_valid = true;
+        st->last_folded = false;
+    }
     *Lp_out = Lp;
     *Rp_out = Rp;
     return HALO_OK;
@@ -798,6 +810,13 @@ static int ipa_round_fold_impl(halo_ipa *st, const uint64_t xi[4], const uint64_
     size_t m = st->m / 2;
     host::Fr x = host::Fr::load(xi), xinv = host::Fr::load(xi_inv);
     int rc;
+    if (st->last_valid && st->m == 2) {  // the fold after the last round: halo_ipa_finish needs its challenge, see there
+        st->last_xi = x;
+        st->last_xi_inv = xinv;
+        st->last_folded = true;
+    } else {
+        st->last_valid = false;
+    }
     if (st->nofold) {
         rc = nofold_s_update(ctx, st->d_s, st->s_len, x, st->d_s2);
         if (!rc) { std::swap(st->d_s, st->d_s2); st->s_len *= 2; }
@@ -835,6 +854,27 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     HALO_CTX(ctx);
     if (st->m != 1) { set_error("ipa_finish: rounds remaining"); return HALO_E_ARG; }
     int rc;
+    static const bool u_from_last_round = !(getenv("HALO_U_FROM_LAST_ROUND") && atoi(getenv("HALO_U_FROM_LAST_ROUND")) == 0);  // development switch
+    if (st->nofold && st->M > 1 && st->last_valid && st->last_folded && u_from_last_round && !st->last_c0.is_zero() && !st->last_c1.is_zero()) {
+        // U = G_final[0] = sum_b s''[b] K[b] with s''[2t + u] = s[t] xi^u (the last fold): U = A + xi B, A / B = the sums of
+        // s[t] K[2t] / s[t] K[2t + 1].  The last round had two coefficients left, so its MSMs were exactly L' = c1 A and
+        // R' = c0 B (k_nofold_expand with m = 2: FL[2t] = c[1] s[t], FR[2t + 1] = c[0] s[t]): U = L' / c1 + (xi / c0) R' -- two
+        // scalar multiples on the host (~80 us, side by side on two threads) instead of one more MSM over the key (0.45 ms at
+        // 2^14 points), and c = c0 + xi^-1 c1 (pcdl.rs:222) without another copy.  A zero coefficient takes the MSM below.
+        host::Fr inv01 = (st->last_c0 * st->last_c1).inv();  // one inversion for both
+        host::Fr a = inv01 * st->last_c0, b = inv01 * st->last_c1 * st->last_xi;  // 1 / c1, xi / c0
+        host::Point Lp = st->last_L, Rp = st->last_R, Ua, Ub;
+        ctx->worker.submit([&Ua, &Lp, &a] { Ua = Lp.mul(a); });
+        Ub = Rp.mul(b);
+        ctx->worker.wait();
+        (Ua + Ub).store_normalized(U);
+        (st->last_c0 + st->last_xi_inv * st->last_c1).store(c);
+        if (ctx->prof.on) {
+            for (int k = 0; k < 3; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
+            ctx->prof.collect();
+        }
+        return HALO_OK;
+    }
     if (st->nofold && st->M > 1) {
         // U = G_final[0] = sum_t s[t] * G0[t]
         host::Point Up;

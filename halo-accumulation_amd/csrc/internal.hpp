@@ -313,6 +313,12 @@ struct halo_ipa {
     uint64_t *d_s = nullptr, *d_s2 = nullptr, *d_FL = nullptr, *d_FR = nullptr;  // M x 4 each
     uint64_t *d_pbar = nullptr;  // n x 4: this shard of p_bar (hiding branch of the sharded open)
     bool pbar_valid = false;     // halo_ipa_hiding_partial has filled d_pbar for this state
+    // The LAST round of a no-fold phase already holds U (abi.hip halo_ipa_finish): with two coefficients c0, c1 left, its MSMs are
+    // L' = c1 A and R' = c0 B over the even / odd points of the key, and U = G_final[0] = A + xi B.  Kept here: L', R' before
+    // their H' terms, c0, c1 (copied to the host with the round's results) and the round's challenge.
+    bool last_valid = false, last_folded = false;
+    halo::host::Point last_L, last_R;
+    halo::host::Fr last_c0, last_c1, last_xi, last_xi_inv;
     bool counted_hot = false;    // this state is counted in ctx->worker's hot count (undone by halo_ipa_destroy)
     bool borrowed = false;       // buffers belong to ctx->ipa_bufs (returned, not freed, by halo_ipa_destroy)
 };

@@ -47,6 +47,37 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def select_fastest(log_n: int = 13):
+    """bench.py's cpu_baseline leg: build BOTH the portable (-march=x86-64-v2) and the host-native (-march=native) library,
+    time one MSM of 2^log_n points with each and keep the faster one for everything that follows -- with this image's gcc 11 the
+    native build is not always the faster one (EPYC 9575F: 0.165 against 0.186 MSM/s at 2^20).  -> {flags: seconds}"""
+    global _lib, LIB_PATH, BUILD_FLAGS, NATIVE
+    import time
+    timings, libs = {}, {}
+    for native in (False, True):
+        NATIVE = native
+        LIB_PATH = os.path.join(HERE, "_build", "liborc_native.so" if native else "liborc.so")
+        BUILD_FLAGS = "-O3 -march=native" if native else "-O3 -march=x86-64-v2"
+        _lib = None
+        try:
+            l = lib()
+        except Exception:  # noqa: BLE001 -- no compiler on this host: the prebuilt portable library is what there is
+            continue
+        n = 1 << log_n
+        gs, (sc, _) = urs_affine(2, n), rng_scalars(7, n)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            msm_affine(gs, sc)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        timings[BUILD_FLAGS] = best
+        libs[BUILD_FLAGS] = (l, LIB_PATH, native)
+    BUILD_FLAGS = min(timings, key=timings.get)
+    _lib, LIB_PATH, NATIVE = libs[BUILD_FLAGS]
+    return timings
+
+
 u64p = C.POINTER(C.c_uint64)
 
 
