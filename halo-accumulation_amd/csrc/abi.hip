@@ -309,6 +309,7 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     for (auto p : ctx->d_batch_scalars) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_wintab) (void)hipHostFree(ctx->h_wintab);
+    for (auto &pair : ctx->ev_piece) for (auto e : pair) if (e) (void)hipEventDestroy(e);
     for (auto st : ctx->streams) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }

@@ -112,6 +112,8 @@ struct MsmWorkspace {
     size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0, cap_hist = 0, cap_windows = 0;
     MsmPlan plan{};          // plan of the MSM in flight on this slot
     bool in_flight = false;
+    int lent_from = -1;      // this slot's workspace and stream run the odd pieces of the large MSM in flight on slot `lent_from`
+    int borrowed = -1;       // ... and that slot remembers which one it borrowed (msm_wait gives it back)
     // hipGraph of the launch sequence, replayed while the same (bases, scalars, n, form, window) repeats
     struct GraphKey {
         const void *bases = nullptr;
@@ -285,6 +287,8 @@ struct halo_ctx {
     halo::HostWorker worker;      // host arithmetic overlapped with the caller's (see HostWorker; multi.hip also runs a shard's HIP calls on it)
     IpaBuffers ipa_bufs;          // reused by every halo_ipa of this context (one at a time; a second one allocates its own)
     uint64_t alloc_epoch = 0;     // bumped whenever this context allocates or frees device memory (see msm.hip, launch graphs)
+    int may_borrow = 0;           // > 0 inside a synchronous MSM call: a large MSM may run its odd pieces on the neighbouring slot (msm.hip)
+    hipEvent_t ev_piece[HALO_SLOTS][2] = {};  // fork / join of those pieces (created on first use)
     // multi-device contexts (multi.hip): one shard context per device over its index block of the key; MSMs over the key fan out
     std::vector<halo_ctx *> shards;
     std::vector<size_t> shard_lo;  // shards.size() + 1 block boundaries
@@ -326,6 +330,12 @@ struct halo_ipa {
 namespace halo {
 
 // ---- msm.hip
+// scope of a synchronous MSM call (nothing else of the caller's can be in flight on the context's other slots meanwhile)
+struct BorrowScope {
+    halo_ctx *c;
+    explicit BorrowScope(halo_ctx *ctx) : c(ctx) { c->may_borrow++; }
+    ~BorrowScope() { c->may_borrow--; }
+};
 // a context's count of its own device (de)allocations
 inline void alloc_epoch_bump(halo_ctx *ctx) { ctx->alloc_epoch++; }
 int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);

@@ -1594,12 +1594,13 @@ int msm_run(halo_ctx *ctx, const uint32_t *d_bases, const uint64_t *d_scalars, b
     // a multi-device context: a large MSM over its own key goes to the shards (multi.hip); short ones are not worth the fan-out
     if (n >= ((size_t)1 << 16) && multi_takes(ctx, d_bases, n))
         return multi_run(ctx, (size_t)(d_bases - ctx->d_bases) / AFF_STRIDE, n, d_scalars, mont, out);
+    BorrowScope scope(ctx);  // synchronous: a large MSM may alternate its pieces over slot 1's workspace (tmsm_enqueue_launches)
     int rc = msm_enqueue(ctx, 0, d_bases, d_scalars, mont, n);
     if (rc) return rc;
     return msm_finish(ctx, 0, out);
 }
 
-int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n);
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n, int partner);
 static int table_build(halo_ctx *ctx);
 static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n);
 
@@ -1688,12 +1689,29 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         int rc = table_build(ctx);
         if (rc) return rc;
     }
+    // A table MSM of more than TBL_PIECE points runs as consecutive pieces.  Inside a synchronous call (msm_run, pcdl::check: the
+    // caller has nothing else in flight) the pieces ALTERNATE over this slot's workspace and stream and the neighbouring slot's:
+    // piece k + 1 sorts and accumulates while piece k's window sums -- latency chains on a few hundred waves -- finish.
+    int partner = -1;
+    if (ctx->may_borrow > 0 && members.count == 1 && ctx->d_table && ctx->tbl.c == 20 && n > TBL_PIECE && table_eligible(ctx, d_bases, members, n) &&
+        !(getenv("HALO_PIECE_ALTERNATE") && atoi(getenv("HALO_PIECE_ALTERNATE")) == 0)) {
+        int cand = slot ^ 1;
+        if (!ctx->wss[cand].in_flight) {
+            if (!ctx->wss[cand].d_counts || ctx->wss[cand].cap_n < ws.cap_n) {
+                if (ctx->wss[cand].d_counts) { alloc_epoch_bump(ctx); workspace_release(ctx->wss[cand]); }
+                if (msm_workspace_alloc(ctx, ws.cap_n, cand) == HALO_OK) partner = cand;
+                else (void)hipGetLastError();  // no room for a second workspace: the pieces run one after the other, same result
+            } else partner = cand;
+        }
+        for (int k = 0; k < 2 && partner >= 0; ++k)
+            if (!ctx->ev_piece[slot][k] && hipEventCreateWithFlags(&ctx->ev_piece[slot][k], hipEventDisableTiming) != hipSuccess) partner = -1;
+    }
     // The launch sequence below is fixed for a given (bases, scalars, n, form, window): the second
     // time the same key arrives it is captured into a hipGraph, afterwards one graph launch replaces
     // ~25 kernel launches (host launch cost matters for the small MSMs of the IPA rounds and of a
     // rank's share of a sharded MSM).  Event profiling needs the individual launches.
     MsmWorkspace::GraphKey key;
-    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1) + 1048576 * (ctx->table_mode + 1);
+    key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1) + 1048576 * (ctx->table_mode + 1) + 4194304 * (partner + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
     // A graph is kept while the same key keeps arriving on this slot and this context has not allocated or freed device
     // memory since it was instantiated (its own workspaces, table, IPA buffers: first use only -- the opens of a loop
@@ -1711,13 +1729,14 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
         ws.plan = ws.graph_plan;
         ws.in_flight = true;
+        if (partner >= 0) { ws.borrowed = partner; ctx->wss[partner].in_flight = true; ctx->wss[partner].lent_from = slot; }
         return HALO_OK;
     }
     bool capture = graphs && key == ws.seen_key;
     ws.seen_key = key;
     if (debug_trace()) fprintf(stderr, "[halo] msm enqueue ctx=%p slot=%d n=%zu batch=%d part=%d/%d capture=%d\n", (void *)ctx, slot, n, members.count, members.part, members.parts, (int)capture);
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
-    int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n);
+    int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
     if (capture) {
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(ctx->streams[slot], &graph);
@@ -1734,6 +1753,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     }
     if (rc) return rc;
     ws.in_flight = true;
+    if (partner >= 0) { ws.borrowed = partner; ctx->wss[partner].in_flight = true; ctx->wss[partner].lent_from = slot; }
     return HALO_OK;
 }
 
@@ -1815,7 +1835,8 @@ static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const M
     if (ctx->n < least || n < least || (tp.c != 20 && 2 * n < ctx->n) || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
-static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece);
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece,
+                              uint64_t *h_dst);
 // the shape of the row / column window sums (k_msm_reduce_rc) for a launch of `sets` bucket sets of B buckets each; per = 0: none
 static RcShape table_rc_shape(int c, uint32_t B, uint32_t sets) {
     static const bool off = getenv("HALO_REDUCE_RC") && atoi(getenv("HALO_REDUCE_RC")) == 0;  // development switch: the older form
@@ -1833,7 +1854,7 @@ static TblPlan table_launch_plan(const halo_ctx *ctx, int count) {
     if (count > 1 && tp.vw_bits < 15 && tp.B >= (1u << 15)) { tp.vw_bits = 15; tp.vw = tp.B >> 15; }
     return tp;
 }
-static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
+static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n, int partner) {
     const TblPlan tp = table_launch_plan(ctx, members.count);
     size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
     uint32_t cpow = 1;  // a batch (small-key plan, one piece) lays its members' bucket sets side by side: a power of two of them
@@ -1844,10 +1865,28 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
         return HALO_E_ARG;
     }
     size_t len = ((n + pieces - 1) / pieces + 3) / 4 * 4, off = 0;
+    // `partner` >= 0: the odd pieces run on that slot's workspace and stream (forked off this stream here, joined below) and
+    // leave their window sums in THIS slot's pinned buffer, where msm_combine_member adds the pieces up.
+    if (pieces < 2) partner = -1;
+    int slot = (int)(&ws - ctx->wss);
+    hipStream_t mine = ctx->stream;
+    if (partner >= 0) {
+        if (2 * tp.vw * cpow > ctx->wss[partner].cap_windows || rc_points(rcs) * cpow > ctx->wss[partner].cap_windows) partner = -1;
+    }
+    if (partner >= 0) {
+        HALO_HIP(hipEventRecord(ctx->ev_piece[slot][0], mine));
+        HALO_HIP(hipStreamWaitEvent(ctx->streams[partner], ctx->ev_piece[slot][0], 0));
+    }
     for (size_t k = 0; k < pieces; ++k, off += len) {
         size_t m = off + len <= n ? len : n - off;  // (n and len are multiples of 4)
-        int rc = tmsm_enqueue_piece(ctx, ws, d_bases + AFF_STRIDE * off, members, off, mont, m, (int)k);
+        bool alt = partner >= 0 && (k & 1);
+        StreamGuard on(ctx, alt ? ctx->streams[partner] : mine);
+        int rc = tmsm_enqueue_piece(ctx, alt ? ctx->wss[partner] : ws, d_bases + AFF_STRIDE * off, members, off, mont, m, (int)k, ws.h_winsum);
         if (rc) return rc;
+    }
+    if (partner >= 0) {
+        HALO_HIP(hipEventRecord(ctx->ev_piece[slot][1], ctx->streams[partner]));
+        HALO_HIP(hipStreamWaitEvent(mine, ctx->ev_piece[slot][1], 0));
     }
     MsmPlan p;
     p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = members.count; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
@@ -1860,7 +1899,8 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     return HALO_OK;
 }
 // one piece: window sums to slot `piece` of d_winsum / h_winsum (sets * vw weighted sums, then sets * vw plain sums)
-static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece) {
+static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece,
+                              uint64_t *h_dst) {
     TblPlan tp = table_launch_plan(ctx, members.count);
     uint32_t cpow = 1;
     while ((int)cpow < members.count) cpow <<= 1;
@@ -1919,7 +1959,7 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
         int rc = rc_mid_enqueue(ctx, ws.d_seg, pts / 2, d_rc);
         if (rc) return rc;
         HALO_HIP(hipGetLastError());
-        HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * pts * 12, d_rc, (size_t)pts * 96, hipMemcpyDeviceToHost, s));
+        HALO_HIP(hipMemcpyAsync(h_dst + (size_t)piece * pts * 12, d_rc, (size_t)pts * 96, hipMemcpyDeviceToHost, s));
         return HALO_OK;
     }
     uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
@@ -1935,16 +1975,16 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(ws.h_winsum + (size_t)piece * 2 * tp.vw * 12, d_out, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
+    HALO_HIP(hipMemcpyAsync(h_dst + (size_t)piece * 2 * tp.vw * 12, d_out, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
     return HALO_OK;
 }
 
 // the launch sequence proper (recorded into a graph when the stream is capturing); sets ws.plan.
 // Wt = W * batch windows go through the sort / accumulate / reduce kernels as if they belonged to one MSM;
 // only the recode (one scalar array per member) and the scatter (one base offset per member) know better.
-int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n) {
+int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n, int partner) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
-    if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members, mont, n);
+    if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
     MsmPlan p = msm_plan(n, ctx->window_bits);
     p.batch = members.count;
     p.w0 = p.W * members.part / members.parts;
@@ -2075,6 +2115,11 @@ int msm_wait(halo_ctx *ctx, int slot, int count) {
     MsmWorkspace &ws = ctx->wss[slot];
     if (ws.plan.batch != count) { set_error("msm: this slot holds a batch of a different size"); return HALO_E_ARG; }
     ws.in_flight = false;
+    if (ws.borrowed >= 0) {  // (the neighbour's launches were joined into this slot's stream: the wait below covers them)
+        ctx->wss[ws.borrowed].in_flight = false;
+        ctx->wss[ws.borrowed].lent_from = -1;
+        ws.borrowed = -1;
+    }
     if (ws.plan.W == 0) return HALO_OK;  // n == 0, or a window shard without windows
     HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
     bool others = false;

@@ -374,7 +374,10 @@ static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z,
     size_t lg_n = st.lg_n, n = d + 1;
     rc = h_coeffs_dev(ctx, st.xis.data(), lg_n, Fr::one(), false, ctx->d_tmp_a);  // h.get_poly().coeffs
     if (rc) return rc;
-    rc = msm_enqueue(ctx, 0, ctx->d_bases, ctx->d_tmp_a, true, n);  // :338, asynchronous
+    {
+        BorrowScope scope(ctx);  // (nothing else of the caller's is in flight during a check: a large MSM may use slot 1 as well)
+        rc = msm_enqueue(ctx, 0, ctx->d_bases, ctx->d_tmp_a, true, n);  // :338, asynchronous
+    }
     if (rc) return rc;
     int rc_rel = succinct_relation(st, z, v, proof);
     std::string rel_err = rc_rel ? halo_last_error() : "";
