@@ -31,6 +31,14 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (PMC counters need rocprofv3 passes of their own -- tools/evidence.sh --
+    so the traffic figures of the JSON line are STATIC, taken from the committed pass named beside them)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return files[-1] if files else None
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: everything else any library prints there during the run (RCCL announces
     # its version on stdout when a communicator is created) is sent to stderr
@@ -272,11 +280,11 @@ def main():
         # HBM-side bytes per launch: PMC counters need a rocprofv3 --pmc pass of their own (tools/evidence.sh), they cannot be
         # read inside this run -- the figure is STATIC, taken from the committed pass named in traffic_source
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if world == 1 and args.log_n == 20 and os.path.exists(pmc):
+        pmc = latest_profile("pmc_traffic.json")
+        if world == 1 and args.log_n == 20 and pmc:
             pj = json.load(open(pmc))
             traffic = pj["kernels"].get(dom, {}).get("traffic_bytes_per_launch")
-            traffic_source = "static: profiles/r03_pmc_traffic.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+            traffic_source = "static: profiles/%s (%s)" % (os.path.basename(pmc), pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"))
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         # VALU view of the same kernel: one mixed XYZZ addition is 1143 v_mad_u64_u32 on the
         # kernel's hot path (counted in the gfx950 ISA), one per point per window; the issue peak is the measured
@@ -295,14 +303,14 @@ def main():
             valu = {"unit": "v_mad_u64_u32 wave-instr/s", "achieved": wave_mads / kern_s, "peak": peak, "frac": wave_mads / kern_s / peak}
             # what the SIMDs did during the kernel, from the committed SQ counter pass (static, like `traffic`): vector
             # instructions issued per 4-cycle issue slot over all 1024 SIMDs, the clock the chip held, parked wave cycles
-            sq = os.path.join(ROOT, "profiles", "r03_sq_msm.json")
-            if world == 1 and args.log_n == 20 and os.path.exists(sq):
+            sq = latest_profile("sq_msm.json")
+            if world == 1 and args.log_n == 20 and sq:
                 k = json.load(open(sq))["kernels"].get(dom)
                 if k:
                     valu["issue_slots_used"] = k["valu_per_quad"]
                     valu["clock_ghz_during_kernel"] = k["clock_ghz"]
                     valu["wave_cycles_parked"] = k["wave_parked"]
-                    valu["issue_source"] = "static: profiles/r03_sq_msm.json (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_ANY ..., one MSM in flight)"
+                    valu["issue_source"] = "static: profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_ANY ..., one MSM in flight)" % os.path.basename(sq)
         result = {
             "metric": "MSMs/sec (Pippenger, Pallas, n=2^%d random scalars/URS points, bit-exact vs CPU)" % args.log_n,
             "value": args.steps / dt, "unit": "MSM/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -416,11 +424,11 @@ def main():
             cfg["depth"] = args.depth
             vk_ms = vprof.get("k_msm_accumulate", (0.0, 0))[0] / 8
             vtraffic, vsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_general.json")
-            if args.log_n == 20 and os.path.exists(pmc):
+            pmc = latest_profile("pmc_traffic_general.json")
+            if args.log_n == 20 and pmc:
                 pj = json.load(open(pmc))
                 vtraffic = pj["kernels"].get("k_msm_accumulate", {}).get("traffic_bytes_per_launch")
-                vsrc = "static: profiles/r04_pmc_traffic_general.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+                vsrc = "static: profiles/%s (%s)" % (os.path.basename(pmc), pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"))
             vach = (96 * n + 64) / (vk_ms * 1e-3) / 1e9 if vk_ms > 0 else 0.0
             result["variable_base"] = {
                 "value": args.var_steps / vdt, "unit": "MSM/s", "ms_per_step": vdt / args.var_steps * 1e3, "solo_latency_ms": median(vsolo) * 1e3,
@@ -502,11 +510,11 @@ def main():
             if dom_o[1]:
                 o_ms, o_alg = dom_o[0], (80 * n if is_fold else 96 * n)
                 o_traffic, o_src = None, None
-                pmc = os.path.join(ROOT, "profiles", "r04_pmc_open_loop.json")
-                if args.log_n == 20 and table_in_place and os.path.exists(pmc):
+                pmc = latest_profile("pmc_open_loop.json")
+                if args.log_n == 20 and table_in_place and pmc:
                     pj = json.load(open(pmc))
                     o_traffic = pj["kernels"].get("k_fold_tab4", {}).get("traffic_bytes_per_launch")
-                    o_src = "static: profiles/r04_pmc_open_loop.json (%s)" % pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/open_loop.py")
+                    o_src = "static: profiles/%s (%s)" % (os.path.basename(pmc), pj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/open_loop.py"))
                 o_ach = o_alg / (o_ms * 1e-3) / 1e9 if o_ms > 0 else 0.0
                 # VALU view: a table fold is ~128 mixed additions per output (2 x 22 comb entries per scalar, three scalars) of ~1143
                 # v_mad_u64_u32 each (the XYZZ mixed addition of the bucket kernel), n / 4 outputs

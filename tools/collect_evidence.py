@@ -25,6 +25,10 @@ stats("prof_open", "open_check_kernel_stats.csv")
 stats("fr_trace", "fr_kernels_kernel_stats.csv")
 cp(os.path.join(ev, "open_timeline.txt"), "open_check_timeline.txt")
 cp(os.path.join(ev, "pmc_traffic.json"), "pmc_traffic.json")
+cp(os.path.join(ev, "pmc_traffic_general.json"), "pmc_traffic_general.json")
+stats("prof_d1_gen", "general_pipeline_depth1_kernel_stats.csv")
+cp(os.path.join(ev, "bench_2_24.json"), "bench_2_24_one_gpu.json")
+cp(os.path.join(ev, "bench_oneproc8_2_24.json"), "rehearsal_oneproc8_2_24_shards_on_1gpu.json")
 cp(os.path.join(ev, "sq_msm.json"), "sq_msm.json")
 cp(os.path.join(ev, "pmc_fr.json"), "pmc_open.json")
 cp(os.path.join(ev, "fr_kernels_events.json"), "fr_kernels_events.json")
