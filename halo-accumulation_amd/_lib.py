@@ -131,6 +131,7 @@ _SIGS = {
     "halo_ctx_info": (C.c_size_t, [C.c_void_p, C.c_int]),
     "halo_set_memory_budget": (C.c_int, [C.c_void_p, C.c_size_t]),
     "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_fold_async": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -401,6 +402,10 @@ class Context:
 
     def set_fold_levels(self, levels):
         check(self.lib.halo_set_fold_levels(self.h, levels))
+
+    def set_fold_async(self, mode):
+        """-1 automatic (opens of <= 2^18 points), 0 never, 1 wherever possible"""
+        check(self.lib.halo_set_fold_async(self.h, int(mode)))
 
     def set_fold_table(self, mode):
         check(self.lib.halo_set_fold_table(self.h, mode))

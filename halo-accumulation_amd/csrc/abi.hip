@@ -75,6 +75,7 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
     HALO_HIP(hipHostMalloc(&ctx->h_wintab, 8192));
     if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;  // HALO_GRAPHS=0: never replay launch graphs
+    if (const char *e = getenv("HALO_FOLD_ASYNC")) ctx->fold_async = atoi(e);  // -1 automatic, 0 every fold in line, 1 beside the rounds wherever possible (halo_set_fold_async)
     return msm_workspace_alloc(ctx, n, 0);
 }
 
@@ -152,6 +153,7 @@ static int ipa_begin_general(halo_ctx *ctx, size_t n, const uint64_t *d_coeffs_p
     st->n = st->m = n;
     int rc = HALO_OK;
     if (hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) { delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
+    if (hipEventCreateWithFlags(&st->ev_fold, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(st->ev); delete st; set_error("ipa_begin: event"); return HALO_E_DEVICE; }
     do {
         // The context's own buffers (sized for the whole key on first use) serve one state at a time: the opens of a
         // prover loop allocate nothing.  A second concurrent state of the same context gets private buffers.
@@ -822,9 +824,10 @@ static int ipa_round_fold_impl(halo_ipa *st, const uint64_t xi[4], const uint64_
         rc = nofold_s_update(ctx, st->d_s, st->s_len, x, st->d_s2);
         if (!rc) { std::swap(st->d_s, st->d_s2); st->s_len *= 2; }
         if (!rc && st->deferred) {  // host copy of the (short) challenge products: s'[2t + u] = s[t] xi^u
-            std::vector<host::Fr> s2(2 * st->s_host.size());
-            for (size_t t = 0; t < st->s_host.size(); ++t) { s2[2 * t] = st->s_host[t]; s2[2 * t + 1] = st->s_host[t] * x; }
-            st->s_host.swap(s2);
+            std::vector<host::Fr> &cur = st->fold_pending ? st->tail_host : st->s_host;  // (a fold under way has taken s_host)
+            std::vector<host::Fr> s2(2 * cur.size());
+            for (size_t t = 0; t < cur.size(); ++t) { s2[2 * t] = cur[t]; s2[2 * t + 1] = cur[t] * x; }
+            cur.swap(s2);
         }
     } else {
         rc = ipa_fold_points(ctx, st->d_G, m, x);
@@ -832,11 +835,53 @@ static int ipa_round_fold_impl(halo_ipa *st, const uint64_t xi[4], const uint64_
     if (!rc) rc = ipa_fold_scalars(ctx, st->d_c, st->d_z, m, x, xinv);
     if (rc) return rc;
     st->m = m;
-    if (st->nofold && st->deferred && st->s_len == 4) {
+    if (st->nofold && st->deferred && st->fold_pending && st->tail_host.size() == 4) {
+        // Two rounds have run beside the fold launched two rounds ago: switch to its output.  The challenge products since
+        // then are s[0..4) (the newest challenge is the lowest index bit and s[0] = 1): nothing to upload, s just gets shorter.
+        HALO_HIP(hipStreamWaitEvent(ctx->streams[0], st->ev_fold, 0));
+        st->G_src = st->fold_dst;
+        st->M = st->fold_m;
+        st->s_len = 4;
+        st->s_host.swap(st->tail_host);
+        st->tail_host.clear();
+        st->fold_pending = false;
+        st->deferred = st->M > kNoFoldSize;
+        if (!st->deferred) return HALO_OK;  // (the key stays as it is for the remaining rounds; s goes on from its 4 entries)
+    }
+    if (st->nofold && st->deferred && !st->fold_pending && st->s_len == 4) {
         // two rounds are due: G[j] <- G[j] + s1 G[j+m] + s2 G[j+2m] + s3 G[j+3m] with one shared doubling chain
+        const size_t Mcur = 4 * m;
+        // Measured (tools/open_loop.py, medians of 11, one box): opens of 2^18 points 9.33 -> 8.99 ms with the folds beside the
+        // rounds; at 2^19 12.35 -> 12.61 and at 2^20 15.68 -> 16.43 (only the last fold beside: 15.89): there the rounds over the
+        // larger key lose more than the hidden fold returns -- a fold's waves sit on every CU (one per SIMD, 232-252 registers,
+        // the lane form 27 KB of LDS) and the rounds' 1024-thread sort blocks (140 KB of LDS) cannot start beside them.
+        // Hence the automatic mode: opens of at most 2^18 points.
+        const bool want_async = ctx->fold_async > 0 || (ctx->fold_async < 0 && st->n <= ((size_t)1 << 18));
+        if (want_async && Mcur <= ((size_t)1 << 18) && m >= 64 && st->g_off + m <= (st->borrowed ? ctx->ipa_bufs.cap_n : st->n)) {
+            // ... BESIDE the next two rounds (see halo_ipa::fold_pending): on the fourth stream, behind whatever wrote the
+            // key it reads (stream 0: an earlier in-line fold; stream 3 itself: the previous fold of this kind)
+            uint32_t *dst = st->d_G + 32 * st->g_off;  // (32 words = one 128-byte point, curve.hpp AFF_STRIDE)
+            HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
+            HALO_HIP(hipStreamWaitEvent(ctx->streams[3], st->ev, 0));
+            {
+                hipStream_t saved = ctx->stream;
+                ctx->stream = ctx->streams[3];
+                rc = ipa_fold_points4(ctx, st->G_src, dst, m, &st->s_host[1]);
+                ctx->stream = saved;
+            }
+            if (rc) return rc;
+            HALO_HIP(hipEventRecord(st->ev_fold, ctx->streams[3]));
+            st->fold_pending = true;
+            st->fold_dst = dst;
+            st->fold_m = m;
+            st->g_off += m;
+            st->tail_host.assign(1, host::Fr::one());
+            return HALO_OK;
+        }
         rc = ipa_fold_points4(ctx, st->G_src, st->d_G, m, &st->s_host[1]);
         if (rc) return rc;
         st->G_src = st->d_G;
+        st->g_off = m;  // (in place from here on would overwrite this key: later folds go behind it)
         st->deferred = m > kNoFoldSize;  // below the switch size the key stays as it is for the remaining rounds
         st->s_host.assign(1, host::Fr::one());
         if (m > 1) return ipa_enter_nofold(st);
@@ -854,6 +899,10 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
     halo_ctx *ctx = st->ctx;
     HALO_CTX(ctx);
     if (st->m != 1) { set_error("ipa_finish: rounds remaining"); return HALO_E_ARG; }
+    if (st->fold_pending) {  // (cannot happen with >= 2 rounds behind every fold launched beside them; kept for safety)
+        HALO_HIP(hipStreamWaitEvent(ctx->streams[0], st->ev_fold, 0));
+        st->fold_pending = false;
+    }
     int rc;
     static const bool u_from_last_round = !(getenv("HALO_U_FROM_LAST_ROUND") && atoi(getenv("HALO_U_FROM_LAST_ROUND")) == 0);  // development switch
     if (st->nofold && st->M > 1 && st->last_valid && st->last_folded && u_from_last_round && !st->last_c0.is_zero() && !st->last_c1.is_zero()) {
@@ -871,7 +920,7 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
         (Ua + Ub).store_normalized(U);
         (st->last_c0 + st->last_xi_inv * st->last_c1).store(c);
         if (ctx->prof.on) {
-            for (int k = 0; k < 3; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
+            for (int k = 0; k < 4; ++k) HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
             ctx->prof.collect();
         }
         return HALO_OK;
@@ -945,7 +994,7 @@ void halo_ipa_destroy(halo_ipa *st) {
     halo_ctx *ctx = st->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->streams[k]);  // folds, the second MSM, the dot products
+        for (int k = 0; k < 4; ++k) (void)hipStreamSynchronize(ctx->streams[k]);  // folds, the second MSM, the dot products, a fold beside the rounds
     }
     if (ctx && st->counted_hot) ctx->worker.add_hot(-1);
     if (st->borrowed && ctx) {
@@ -960,6 +1009,7 @@ void halo_ipa_destroy(halo_ipa *st) {
         (void)hipFree(st->d_pbar);
     }
     if (st->ev) (void)hipEventDestroy(st->ev);
+    if (st->ev_fold) (void)hipEventDestroy(st->ev_fold);
     delete st;
 }
 size_t halo_ipa_len(const halo_ipa *st) { return st ? st->m : 0; }
@@ -1234,6 +1284,11 @@ int halo_set_batch_verify(halo_ctx *ctx, int on) {
 int halo_set_fold_levels(halo_ctx *ctx, int levels) {
     if (!ctx || (levels != 1 && levels != 2)) { set_error("fold levels must be 1 or 2"); return HALO_E_ARG; }
     ctx->fold_levels = levels;
+    return HALO_OK;
+}
+int halo_set_fold_async(halo_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) { set_error("fold async mode must be -1 (automatic), 0 (never) or 1 (wherever possible)"); return HALO_E_ARG; }
+    ctx->fold_async = mode;
     return HALO_OK;
 }
 int halo_set_fold_table(halo_ctx *ctx, int mode) {

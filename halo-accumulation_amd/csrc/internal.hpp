@@ -272,6 +272,7 @@ struct halo_ctx {
     std::atomic<int> foldtab_alloc_state{0};
     uint32_t *foldtab_pending = nullptr, *foldtab_pending_tmp = nullptr;
     int fold_levels = 2;                   // halving rounds folded into G at a time (1: every round; 2: every other round, k_fold_points4)
+    int fold_async = -1;                   // folds of keys of <= 2^18 points beside the next two rounds: -1 in opens of <= 2^18 points (measured), 0 never, 1 always (halo_set_fold_async)
     // scratch for host-pointer entry points
     uint64_t *d_tmp_a = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr;
     size_t tmp_words = 0;
@@ -323,6 +324,16 @@ struct halo_ipa {
     bool last_valid = false, last_folded = false;
     halo::host::Point last_L, last_R;
     halo::host::Fr last_c0, last_c1, last_xi, last_xi_inv;
+    // A two-level fold of a key of at most 2^18 points is a latency chain on one wave per SIMD (1.6 and 1.1 ms in a 2^20 open):
+    // it runs on the context's fourth stream BESIDE the next two rounds, which keep reading the unfolded key (abi.hip
+    // ipa_round_fold_impl).  fold_pending: launched, not yet switched to; fold_dst / fold_m: its output; tail_host: the products
+    // of the challenges hashed since (they are the first entries of d_s and the scalars of the fold after this one);
+    // g_off: points of d_G already taken by earlier keys (the folds no longer run in place).
+    bool fold_pending = false;
+    uint32_t *fold_dst = nullptr;
+    size_t fold_m = 0, g_off = 0;
+    std::vector<halo::host::Fr> tail_host;
+    hipEvent_t ev_fold = nullptr;
     bool counted_hot = false;    // this state is counted in ctx->worker's hot count (undone by halo_ipa_destroy)
     bool borrowed = false;       // buffers belong to ctx->ipa_bufs (returned, not freed, by halo_ipa_destroy)
 };

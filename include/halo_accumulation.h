@@ -308,6 +308,12 @@ int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
 /* IPA tuning: 2 (default) folds G every other round, two halvings at once with one shared doubling chain, the rounds in
  * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */
 int halo_set_fold_levels(halo_ctx *ctx, int levels);
+/* IPA tuning: a two-level fold of a key of at most 2^18 points (a latency chain on one wave per SIMD) can run on the context's
+ * fourth stream BESIDE the next two rounds, which then take their L, R from the key it reads.  -1 (default): in opens of at
+ * most 2^18 points, where it pays (9.3 -> 9.0 ms at 2^18; at 2^20 the rounds over the larger key lose more than the hidden
+ * fold returns: 15.7 -> 16.4 ms); 0: every fold in line; 1: wherever possible.  Environment
+ * HALO_FOLD_ASYNC=-1/0/1 at context creation.  Results are identical either way. */
+int halo_set_fold_async(halo_ctx *ctx, int mode);
 /* IPA tuning: comb table for the first fold of an open whose size is the context's key (E[w][d][i] = d 64^w G_i: 22
  * windows x 32 multiples x 64 bytes per point of the upper three quarters of the key = 33 KiB x n: 35.4 GB at n = 2^20, plus a
  * 4.6 GB temporary while it is built; ~0.2 s to build; the scalars are split with the curve's endomorphism, 2 x 22 entries per

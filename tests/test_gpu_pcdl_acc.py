@@ -98,18 +98,21 @@ def test_u_check(hal, ctx, ipa_mode):
     assert [orc.fr_from_mont(c) for c in ctx.h_coeffs(xm)] == [1, 3, 2, 6, 1, 3, 2, 6]
 
 
-@pytest.fixture(params=[(0, 1, 0), (1 << 16, 2, -1), (16, 1, 0), (0, 2, 0), (16, 2, 0), (0, 2, 1), (16, 2, 1)],
+@pytest.fixture(params=[(0, 1, 0), (1 << 16, 2, -1), (16, 1, 0), (0, 2, 0), (16, 2, 0), (0, 2, 1), (16, 2, 1), (64, 2, 0, 1), (16, 2, 1, 1), (0, 2, 0, 1)],
                 ids=["always-fold", "default", "switch-at-16", "two-level-folds-to-the-end", "two-level-folds-switch-at-16",
-                     "fold-table-two-level-folds-to-the-end", "fold-table-switch-at-16"])
+                     "fold-table-two-level-folds-to-the-end", "fold-table-switch-at-16", "folds-beside-the-rounds-switch-at-64",
+                     "fold-table-folds-beside-the-rounds-switch-at-16", "folds-beside-the-rounds-to-the-end"])
 def ipa_mode(request, ctx):
     """Every IPA strategy must give the reference's results: folding G every round (k_fold_points), every other round
     (two halvings per pass, k_fold_points4, L/R from MSMs over the unfolded key in between), the first of those passes from
-    the comb table over the context's key (k_fold_tab4: only when the open has the size of the key) and the no-fold late
-    rounds (MSMs over the fixed folded key)."""
+    the comb table over the context's key (k_fold_tab4: only when the open has the size of the key), the no-fold late
+    rounds (MSMs over the fixed folded key), and the two-level folds launched BESIDE the next two rounds (halo_set_fold_async)."""
     ctx.set_ipa_switch(request.param[0])
     ctx.set_fold_levels(request.param[1])
     ctx.set_fold_table(request.param[2])
+    ctx.set_fold_async(request.param[3] if len(request.param) > 3 else 0)  # (folds of >= 64 outputs on the fourth stream, beside the next two rounds)
     yield request.param
+    ctx.set_fold_async(-1)
     ctx.set_ipa_switch(1 << 14)
     ctx.set_fold_levels(2)
     ctx.set_fold_table(0)   # (release the table)
@@ -229,6 +232,38 @@ def test_open_check_matches_oracle(hal, ctx, pp, n, hiding, ipa_mode):
     bad = pi.copy(); bad[2 + 24 * (n.bit_length() - 1): 2 + 24 * (n.bit_length() - 1) + 12] = C
     with pytest.raises(ValueError):
         pcdl.check_proof(ctx, C, d, z, v, bad)
+
+
+@pytest.mark.parametrize("lg", [16, 18])
+def test_folds_beside_the_rounds_give_the_same_proofs(hal, lg):
+    """halo_set_fold_async: a two-level fold of a key of <= 2^18 points runs on the fourth stream while the next two rounds take
+    their L, R from the key it reads; the proof (hiding and not) must be the one the in-line folds give, and the default
+    (automatic: opens of <= 2^18 points) is one of the two."""
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << lg
+    d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        c.set_fold_table(0)
+        dv = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
+        c.rng_scalars_dev(0xA51C + lg, n + 2, dv.data_ptr())
+        zw = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64).reshape(2, 4))
+        v = None
+        for w in (None, zw[1]):
+            C = pcdl.commit_dev(c, dv.data_ptr(), n, d, w)
+            proofs = {}
+            for mode in (0, 1, -1):
+                c.set_fold_async(mode)
+                for rep in range(2):  # (the second open replays the launch graphs of the first)
+                    rng = [99]
+                    proofs[(mode, rep)] = (pcdl.open_dev(c, rng, dv.data_ptr(), n, C, d, zw[0], w).tolist(), rng[0])
+            assert all(p == proofs[(0, 0)] for p in proofs.values())
+            if v is None:
+                v = c.poly_eval(np.ascontiguousarray(dv[: 4 * n].cpu().numpy().view(np.uint64).reshape(n, 4)), zw[0])
+            pcdl.check_proof(c, C, d, zw[0], v, np.array(proofs[(1, 0)][0], dtype=np.uint64))
+    finally:
+        c.close()
 
 
 def test_commit_open_asserts(hal, ctx):
