@@ -1,5 +1,5 @@
 /* integration/harness.c -- the call sequence of the patched pcdl::open (integration/pcdl_rs.patch, INTEGRATION.md
- * section 3), written in plain C against include/halo_accumulation.h and compared with the library's own
+ * section 3) and of the patched AccumulatedHPolys (integration/acc_rs.patch), written in plain C against include/halo_accumulation.h and compared with the library's own
  * halo_pcdl_open / verified with halo_pcdl_check.  What Rust keeps doing in the shim -- rho_0! and the inverse
  * (pcdl.rs:212-213) -- is done here by halo_open_start / halo_open_combine (the host steps the library exports for the
  * sharded open; with P = 1 they reduce to exactly that).
@@ -89,6 +89,45 @@ int main(int argc, char **argv) {
     free(gs);
     printf("point_dot_affine routes agree: %s\n", routes ? "yes" : "NO");
     same = same && routes;
+    /* acc_rs.patch: AccumulatedHPolys::get_poly / eval (acc.rs:85-106) through ffi::h_accumulate / ffi::h_eval_batch.  Checked
+     * with what the C ABI itself offers: the commitment is linear, so commit(h_0 + sum a_i h_i) must equal
+     * commit(h_0) + sum a_i commit(h_i) (halo_h_commit per polynomial, the sum by halo_msm_points); and h_i(z) from the batch
+     * must equal halo_poly_eval over h_i's expanded coefficients. */
+    int acc_ok = 1;
+    {
+        enum { M = 3 };
+        uint64_t xis[M * 64 * 4], alphas[M * 4], h0[8], one_z[8];
+        memset(xis, 0, sizeof xis); memset(alphas, 0, sizeof alphas); memset(h0, 0, sizeof h0);
+        for (size_t i = 0; i < M; i++) {
+            for (size_t k = 0; k <= lg; k++) {
+                uint64_t *x = xis + 4 * (i * (lg + 1) + k);
+                x[0] = 0xD1B54A32D192ED03ull * (k + 1) + i; x[1] = 0x94D049BB133111EBull ^ (k << 8 | i); x[3] = 0x0F00000ull + 16 * k + i;
+            }
+            alphas[4 * i] = 0xA0761D6478BD642Full + i; alphas[4 * i + 2] = i + 1; alphas[4 * i + 3] = 0x2000000ull + i;
+        }
+        h0[0] = 7; h0[3] = 0x111111; h0[4] = 9; h0[7] = 0x222222;
+        CK(halo_powers(ctx, z, 2, one_z)); /* one_z[0..4) = 1 in the library's scalar form */
+        uint64_t *acc = malloc(n * 32), *hi = malloc(n * 32), pts[(M + 1) * 12], sc[(M + 1) * 4], lhs[12], rhs[12], ev[M * 4], ev1[4];
+        CK(halo_h_accumulate(ctx, h0, xis, alphas, M, lg, acc));
+        CK(halo_pcdl_commit(ctx, acc, n, d, NULL, lhs));
+        CK(halo_pcdl_commit(ctx, h0, n < 2 ? n : 2, d, NULL, pts));
+        memcpy(sc, one_z, 32);
+        for (size_t i = 0; i < M; i++) {
+            CK(halo_h_commit(ctx, xis + 4 * i * (lg + 1), lg, pts + 12 * (i + 1)));
+            memcpy(sc + 4 * (i + 1), alphas + 4 * i, 32);
+        }
+        CK(halo_msm_points(ctx, pts, sc, M + 1, rhs));
+        acc_ok = memcmp(lhs, rhs, 96) == 0;
+        CK(halo_h_eval_batch(ctx, xis, M, lg, z, ev));
+        for (size_t i = 0; i < M; i++) {
+            CK(halo_h_coeffs(ctx, xis + 4 * i * (lg + 1), lg, hi));
+            CK(halo_poly_eval(ctx, hi, n, z, ev1));
+            acc_ok = acc_ok && memcmp(ev + 4 * i, ev1, 32) == 0;
+        }
+        free(acc); free(hi);
+    }
+    printf("acc.rs get_poly / eval through h_accumulate / h_eval_batch: %s\n", acc_ok ? "yes" : "NO");
+    same = same && acc_ok;
     printf("lg_n=%zu  shim loop == halo_pcdl_open: %s   check(a)=%d check(b)=%d   wire round trip: %s (%zu bytes)\n", lg, same ? "yes" : "NO", ok_a,
            ok_b, wire ? "yes" : "NO", blen);
     halo_ctx_destroy(ctx);

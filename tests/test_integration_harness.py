@@ -35,3 +35,4 @@ def test_harness_runs(tmp_path, lg):
     out = subprocess.run([exe, str(lg)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shim loop == halo_pcdl_open: yes" in out.stdout and "wire round trip: yes" in out.stdout
+    assert "acc.rs get_poly / eval through h_accumulate / h_eval_batch: yes" in out.stdout

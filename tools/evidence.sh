@@ -15,8 +15,8 @@ if [ "$PART" != B ]; then
 step pytest;  timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1 || { tail -5 $OUT/pytest_gpu.txt; exit 1; }
 tail -1 $OUT/pytest_gpu.txt
 step bench;   timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-step prof_d4; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d4 -- python bench.py --steps 40 --warmup 4 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --min-seconds 0 > $OUT/prof_d4.log 2>&1 || exit 1
-step prof_d1; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1 -- python bench.py --steps 40 --warmup 4 --depth 1 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --min-seconds 0 > $OUT/prof_d1.log 2>&1 || exit 1
+step prof_d4; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d4 -- python bench.py --steps 40 --warmup 4 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --var-steps 0 --min-seconds 0 > $OUT/prof_d4.log 2>&1 || exit 1
+step prof_d1; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1 -- python bench.py --steps 40 --warmup 4 --depth 1 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --var-steps 0 --min-seconds 0 > $OUT/prof_d1.log 2>&1 || exit 1
 step prof_open; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_open -- python tools/open_loop.py 20 5 > $OUT/prof_open.log 2>&1 || exit 1
 python tools/trace_timeline.py $(find $OUT/prof_open -name "*kernel_trace.csv" | head -1) > $OUT/open_timeline.txt 2>&1
 step pmc_fetch; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_fetch.log 2>&1 || exit 1
