@@ -77,19 +77,26 @@ static void fe_neg(fe *r, const fe *a, const field_t *F) {
 }
 static void fe_dbl(fe *r, const fe *a, const field_t *F) { fe_add(r, a, a, F); }
 
-/* CIOS Montgomery multiplication */
+/* CIOS Montgomery multiplication, the four rows written out.  Both Pasta moduli are below 2^255, so the running value stays
+ * below 2 p < 2^256 and needs no fifth word: ark-ff's "no-carry" variant for moduli with a spare top bit
+ * (ark-ff 0.5 montgomery_backend.rs, mul_assign: `can_use_no_carry_mul_optimization`). */
+#define MUL_ROW(bi) do { \
+        u128 c = (u128)a0 * (bi) + t0; u64 lo = (u64)c; c >>= 64; \
+        u64 m = lo * inv; \
+        u128 k = (u128)m * p0 + lo; k >>= 64; \
+        c += (u128)a1 * (bi) + t1; k += (u128)m * p1 + (u64)c; t0 = (u64)k; c >>= 64; k >>= 64; \
+        c += (u128)a2 * (bi) + t2; k += (u128)m * p2 + (u64)c; t1 = (u64)k; c >>= 64; k >>= 64; \
+        c += (u128)a3 * (bi) + t3; k += (u128)m * p3 + (u64)c; t2 = (u64)k; c >>= 64; k >>= 64; \
+        t3 = (u64)c + (u64)k; \
+    } while (0)
 static void fe_mul(fe *r, const fe *a, const fe *b, const field_t *F) {
-    u64 t[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
-        c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
-        u64 m = t[0] * F->inv;
-        c = (u128)m * F->p[0] + t[0]; c >>= 64;
-        for (int j = 1; j < 4; j++) { c += (u128)m * F->p[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
-        c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
-    }
-    if (t[4] || ge4(t, F->p)) sub4(t, t, F->p);
+    const u64 a0 = a->l[0], a1 = a->l[1], a2 = a->l[2], a3 = a->l[3];
+    const u64 b0 = b->l[0], b1 = b->l[1], b2 = b->l[2], b3 = b->l[3];
+    const u64 p0 = F->p[0], p1 = F->p[1], p2 = F->p[2], p3 = F->p[3], inv = F->inv;
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    MUL_ROW(b0); MUL_ROW(b1); MUL_ROW(b2); MUL_ROW(b3);
+    u64 t[4] = {t0, t1, t2, t3};
+    if (ge4(t, F->p)) sub4(t, t, F->p);
     memcpy(r->l, t, 32);
 }
 static void fe_sqr(fe *r, const fe *a, const field_t *F) { fe_mul(r, a, a, F); }
