@@ -78,6 +78,13 @@ def test_no_cpu_fallback(hal):
     out = np.zeros(12, dtype=np.uint64)
     assert lib.halo_msm(None, 0, 0, None, 1, hal._lib.ptr(out)) == hal._lib.HALO_E_ARG
     assert lib.halo_ipa_finish(None, hal._lib.ptr(out), hal._lib.ptr(out)) == hal._lib.HALO_E_ARG
+    # this round's entry points: a null context is an argument error, never a crash; halo_ctx_info of nothing is 0
+    assert lib.halo_set_memory_budget(None, 1 << 30) != 0 and lib.halo_set_fold_async(None, 1) == hal._lib.HALO_E_ARG
+    assert all(lib.halo_ctx_info(None, what) == 0 for what in range(8))
+    # the sharded entry points check what every rank passes alike before any collective could be entered
+    z4 = np.zeros(4, dtype=np.uint64)
+    proof = np.zeros(lib.halo_proof_words(6), dtype=np.uint64)
+    assert lib.halo_pcdl_check_sharded(None, 2, 0, hal._lib.ptr(out), 63, hal._lib.ptr(z4), hal._lib.ptr(z4), hal._lib.ptr(proof), None, None) != 0
 
 
 def test_product_does_not_import_oracle():

@@ -961,6 +961,32 @@ def test_memory_budget_bounds_the_optional_tables_of_all_contexts_on_a_device(ha
         b.close()
 
 
+def test_memory_budget_from_the_environment():
+    """HALO_MEMORY_BUDGET replaces the default budget for the whole process (for hosts that cannot call the setter: the Rust
+    shim); 0 = no optional memory: the table-free pipeline, same point as the oracle's."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, halo_accumulation_amd as h, orc\n"
+        "n = 1 << 17\n"
+        "c = h._lib.Context(urs_n=n)\n"
+        "sc, _ = orc.rng_scalars(11, n)\n"
+        "got = c.msm(sc)\n"
+        "assert got.tolist() == orc.msm_affine(c.read_bases(), sc).tolist()\n"
+        "print(c.info(3), c.info(0), c.info(6), c.info(4))\n"
+    ) % (ROOT, os.path.join(ROOT, "oracle"))
+    for env_val, want_budget, table in (("0", 0, False), ("64M", 64 << 20, False), ("1g", 1 << 30, True)):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HALO_MEMORY_BUDGET=env_val))
+        assert out.returncode == 0, out.stderr[-1500:]
+        budget, tab, status, used = [int(x) for x in out.stdout.split()[-4:]]
+        assert budget == want_budget
+        if table:
+            assert tab == 15 * 128 * (1 << 17) and status == 2 and used == tab
+        else:
+            assert tab == 0 and status == 3 and used == 0
+
+
 def test_sharded_entry_points_report_misuse_and_a_failing_collective(hal):
     """halo_pcdl_open_sharded / _check_sharded: a stride that is no power of two, an offset past it, ranks without an
     all-gather, and a collective that fails (a Python exception inside the callback must surface, not unwind the C frame)."""
