@@ -8,6 +8,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +31,131 @@ struct FrP {
     static constexpr u64 R2[4] = {0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL};
     static constexpr u64 INV = 0x8c46eb20ffffffffULL;
 };
+
+// ---- modular inverse by 62 division steps at a time (Bernstein-Yang "safegcd", in the variable-time form published with
+// libsecp256k1's modinv64: transition matrices from the low 64 bits of f and g, applied to f, g and to the cofactors d, e in
+// signed 62-bit limbs).  Every value inverted on the host is public (proof points, challenges), so variable time is fine.
+// ~1.4 us for a 255-bit value against ~9.5 us for the Fermat power: an open has two of them on its critical path per round
+// (the normalisation of L / R for the transcript, then xi^-1).  tests/native/host_math_sanitize.cpp compares the two.
+namespace modinv {
+typedef __int128 i128;
+struct S62 { int64_t v[5]; };  // sum v[i] 2^(62 i); limbs 0..3 in [0, 2^62), limb 4 signed
+struct T22 { int64_t u, v, q, r; };  // 2^62 x the transition matrix of 62 division steps
+static constexpr int64_t M62 = (int64_t)((~(uint64_t)0) >> 2);
+inline int64_t divsteps_62_var(int64_t eta, uint64_t f0, uint64_t g0, T22 *t) {
+    uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0, m;
+    uint32_t w;
+    int i = 62, limit, zeros;
+    for (;;) {
+        zeros = __builtin_ctzll(g | (~(uint64_t)0 << i));  // (the sentinel bit stops the count at i)
+        g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {  // swap: (f, g) <- (g, -f), and cancel up to 6 low bits of g at once
+            uint64_t tmp;
+            eta = -eta;
+            tmp = f; f = g; g = (uint64_t)0 - tmp;
+            tmp = u; u = q; q = (uint64_t)0 - tmp;
+            tmp = v; v = r; r = (uint64_t)0 - tmp;
+            limit = ((int)eta + 1) > i ? i : ((int)eta + 1);
+            m = (~(uint64_t)0 >> (64 - limit)) & 63u;
+            w = (uint32_t)((f * g * (f * f - 2)) & m);
+        } else {        // up to 4 bits
+            limit = ((int)eta + 1) > i ? i : ((int)eta + 1);
+            m = (~(uint64_t)0 >> (64 - limit)) & 15u;
+            w = (uint32_t)(f + (((f + 1) & 4) << 1));
+            w = (uint32_t)((((uint64_t)0 - (uint64_t)w) * g) & m);
+        }
+        g += f * w; q += u * w; r += v * w;
+    }
+    t->u = (int64_t)u; t->v = (int64_t)v; t->q = (int64_t)q; t->r = (int64_t)r;
+    return eta;
+}
+// (d, e) <- t (d, e) / 2^62 mod M, both kept in (-2M, M)
+inline void update_de_62(S62 *d, S62 *e, const T22 *t, const S62 &mod, uint64_t modinv62) {
+    const int64_t d0 = d->v[0], d1 = d->v[1], d2 = d->v[2], d3 = d->v[3], d4 = d->v[4];
+    const int64_t e0 = e->v[0], e1 = e->v[1], e2 = e->v[2], e3 = e->v[3], e4 = e->v[4];
+    const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
+    const int64_t sd = d4 >> 63, se = e4 >> 63;
+    int64_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    i128 cd = (i128)u * d0 + (i128)v * e0, ce = (i128)q * d0 + (i128)r * e0;
+    md -= (int64_t)((modinv62 * (uint64_t)cd + (uint64_t)md) & (uint64_t)M62);  // so that the low 62 bits below vanish
+    me -= (int64_t)((modinv62 * (uint64_t)ce + (uint64_t)me) & (uint64_t)M62);
+    cd += (i128)mod.v[0] * md; ce += (i128)mod.v[0] * me;
+    cd >>= 62; ce >>= 62;
+    cd += (i128)u * d1 + (i128)v * e1 + (i128)mod.v[1] * md; ce += (i128)q * d1 + (i128)r * e1 + (i128)mod.v[1] * me;
+    d->v[0] = (int64_t)cd & M62; cd >>= 62; e->v[0] = (int64_t)ce & M62; ce >>= 62;
+    cd += (i128)u * d2 + (i128)v * e2 + (i128)mod.v[2] * md; ce += (i128)q * d2 + (i128)r * e2 + (i128)mod.v[2] * me;
+    d->v[1] = (int64_t)cd & M62; cd >>= 62; e->v[1] = (int64_t)ce & M62; ce >>= 62;
+    cd += (i128)u * d3 + (i128)v * e3 + (i128)mod.v[3] * md; ce += (i128)q * d3 + (i128)r * e3 + (i128)mod.v[3] * me;
+    d->v[2] = (int64_t)cd & M62; cd >>= 62; e->v[2] = (int64_t)ce & M62; ce >>= 62;
+    cd += (i128)u * d4 + (i128)v * e4 + (i128)mod.v[4] * md; ce += (i128)q * d4 + (i128)r * e4 + (i128)mod.v[4] * me;
+    d->v[3] = (int64_t)cd & M62; cd >>= 62; e->v[3] = (int64_t)ce & M62; ce >>= 62;
+    d->v[4] = (int64_t)cd; e->v[4] = (int64_t)ce;
+}
+// (f, g) <- t (f, g) / 2^62 over the `len` limbs still in use
+inline void update_fg_62_var(int len, S62 *f, S62 *g, const T22 *t) {
+    const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
+    int64_t fi = f->v[0], gi = g->v[0];
+    i128 cf = (i128)u * fi + (i128)v * gi, cg = (i128)q * fi + (i128)r * gi;
+    cf >>= 62; cg >>= 62;
+    for (int i = 1; i < len; ++i) {
+        fi = f->v[i]; gi = g->v[i];
+        cf += (i128)u * fi + (i128)v * gi; cg += (i128)q * fi + (i128)r * gi;
+        f->v[i - 1] = (int64_t)cf & M62; cf >>= 62;
+        g->v[i - 1] = (int64_t)cg & M62; cg >>= 62;
+    }
+    f->v[len - 1] = (int64_t)cf; g->v[len - 1] = (int64_t)cg;
+}
+inline S62 to_s62(const uint64_t x[4]) {
+    S62 r;
+    r.v[0] = (int64_t)(x[0] & (uint64_t)M62); r.v[1] = (int64_t)(((x[0] >> 62) | (x[1] << 2)) & (uint64_t)M62);
+    r.v[2] = (int64_t)(((x[1] >> 60) | (x[2] << 4)) & (uint64_t)M62); r.v[3] = (int64_t)(((x[2] >> 58) | (x[3] << 6)) & (uint64_t)M62);
+    r.v[4] = (int64_t)(x[3] >> 56);
+    return r;
+}
+// x^-1 mod M as plain integers (x in [1, M), M odd and below 2^255); out in [0, M)
+inline void inverse(const uint64_t x[4], const uint64_t M[4], uint64_t out[4]) {
+    const S62 mod = to_s62(M);
+    uint64_t minv = 1;
+    for (int i = 0; i < 6; i++) minv *= 2 - M[0] * minv;  // M^-1 mod 2^64 (Newton)
+    const uint64_t modinv62 = minv & (uint64_t)M62;
+    S62 d = {{0, 0, 0, 0, 0}}, e = {{1, 0, 0, 0, 0}}, f = mod, g = to_s62(x);
+    int len = 5;
+    int64_t eta = -1;  // eta = -delta, delta starts at 1
+    for (;;) {
+        T22 t;
+        eta = divsteps_62_var(eta, (uint64_t)f.v[0], (uint64_t)g.v[0], &t);
+        update_de_62(&d, &e, &t, mod, modinv62);
+        update_fg_62_var(len, &f, &g, &t);
+        if (g.v[0] == 0) {
+            int64_t any = 0;
+            for (int j = 1; j < len; ++j) any |= g.v[j];
+            if (any == 0) break;  // g = 0: f = +-1 and d = +-x^-1
+        }
+        const int64_t fn = f.v[len - 1], gn = g.v[len - 1];
+        int64_t cond = ((int64_t)len - 2) >> 63;
+        cond |= fn ^ (fn >> 63);
+        cond |= gn ^ (gn >> 63);
+        if (cond == 0) {  // the top limbs of f and g are 0 or -1: fold their sign into the limb below
+            f.v[len - 2] |= (int64_t)((uint64_t)fn << 62);
+            g.v[len - 2] |= (int64_t)((uint64_t)gn << 62);
+            --len;
+        }
+    }
+    // d in (-2M, M), to be negated if f = -1: into [0, M)
+    int64_t r[5] = {d.v[0], d.v[1], d.v[2], d.v[3], d.v[4]};
+    auto add_mod_if = [&](int64_t mask) { for (int i = 0; i < 5; ++i) r[i] += mod.v[i] & mask; };
+    auto carry = [&]() { for (int i = 0; i < 4; ++i) { r[i + 1] += r[i] >> 62; r[i] &= M62; } };
+    add_mod_if(r[4] >> 63);
+    const int64_t neg = f.v[len - 1] >> 63;
+    for (int i = 0; i < 5; ++i) r[i] = (r[i] ^ neg) - neg;
+    carry();
+    add_mod_if(r[4] >> 63);
+    carry();
+    out[0] = (uint64_t)r[0] | ((uint64_t)r[1] << 62); out[1] = ((uint64_t)r[1] >> 2) | ((uint64_t)r[2] << 60);
+    out[2] = ((uint64_t)r[2] >> 4) | ((uint64_t)r[3] << 58); out[3] = ((uint64_t)r[3] >> 6) | ((uint64_t)r[4] << 56);
+}
+}  // namespace modinv
 
 template <class P>
 struct Fp {
@@ -136,11 +262,22 @@ struct Fp {
         }
         return acc;
     }
-    // Fermat inverse; caller checks for zero (ark-ff inverse() -> None)
-    Fp inv() const {
+    // Fermat inverse (the slow, obviously right one: kept as the cross-check of inv())
+    Fp inv_fermat() const {
         u64 e[4], two[4] = {2, 0, 0, 0};
         sub_limbs(e, P::M, two);
         return pow(e);
+    }
+    // inverse; caller checks for zero (ark-ff inverse() -> None; zero in gives zero out, as the Fermat power does).
+    // The limbs hold a = x R: the plain integer inverse of a is x^-1 R^-1, and one Montgomery product with R^3 makes it x^-1 R.
+    Fp inv() const {
+        if (is_zero()) return *this;
+        static const bool use_fermat = getenv("HALO_HOST_INV_FERMAT") != nullptr;  // development switch for A/B runs
+        if (use_fermat) return inv_fermat();
+        static const Fp R3 = Fp{{P::R2[0], P::R2[1], P::R2[2], P::R2[3]}} * Fp{{P::R2[0], P::R2[1], P::R2[2], P::R2[3]}};
+        Fp r;
+        modinv::inverse(l, P::M, r.l);
+        return r * R3;
     }
 };
 
