@@ -446,6 +446,17 @@ def test_table_memory_failure_and_release(hal, monkeypatch):
     try:
         for _ in range(3):
             assert bad.msm(sc).tolist() == want.tolist()
+        assert bad.info(0) == 0 and bad.info(6) == 4
+        # no latch: with the memory back, the table is built at the attempt after the back-off (64 eligible MSMs)
+        monkeypatch.delenv("HALO_TEST_TABLE_FAIL")
+        built_after = None
+        for k in range(70):
+            assert bad.msm(sc).tolist() == want.tolist()
+            if bad.info(0):
+                built_after = k + 1
+                break
+        assert built_after is not None and 55 <= built_after <= 64, built_after
+        assert bad.info(6) == 2 and bad.msm(sc).tolist() == want.tolist()
     finally:
         bad.close()
 

@@ -592,7 +592,8 @@ def test_open_with_fold_table_and_an_infinity_in_the_key(hal):
 
 
 def test_fold_table_memory_failure_falls_back(hal, monkeypatch):
-    """no memory for the comb table: one line on stderr, the generic fold kernel runs, same proof, no second attempt"""
+    """no memory for the comb table: one line on stderr, the generic fold kernel runs, same proof, no attempt per open -- and a
+    new attempt after the back-off, which succeeds once the memory is there"""
     from halo_accumulation_amd import pcdl
     n, d = 1 << 15, (1 << 15) - 1
     c = hal._lib.Context(urs_n=n)
@@ -606,7 +607,20 @@ def test_fold_table_memory_failure_falls_back(hal, monkeypatch):
         c.set_fold_table(1)
         for _ in range(2):
             assert pcdl.open(c, [9], coeffs, C, d, zw[0]).tolist() == want.tolist()
-        assert c.info(1) == 0
+        assert c.info(1) == 0 and c.info(5) == 4, "allocation failed: status 4, tried again later"
+        # no latch.  The memory is back (the hook is gone): the table is tried again after the back-off -- eight more
+        # opens -- without any call from the caller, and nothing it held during the failed attempts stayed on the budget's books
+        monkeypatch.delenv("HALO_TEST_TABLE_FAIL")
+        used = c.info(4)
+        built_after = None
+        for k in range(12):
+            assert pcdl.open(c, [9], coeffs, C, d, zw[0]).tolist() == want.tolist()
+            if c.info(1):
+                built_after = k + 1
+                break
+        assert built_after is not None and 2 <= built_after <= 9, built_after
+        assert c.info(5) == 2 and c.info(4) == used + c.info(1)
+        assert pcdl.open(c, [9], coeffs, C, d, zw[0]).tolist() == want.tolist()  # through the table
     finally:
         c.close()
 
