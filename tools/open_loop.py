@@ -15,6 +15,7 @@ DEV = "host" not in sys.argv[3:]  # default: the polynomial is resident in devic
 n = 1 << lg; d = n - 1
 ctx = h._lib.Context(urs_n=n)
 if os.environ.get("REDUCE_SPAN"): ctx.set_reduce_span(int(os.environ["REDUCE_SPAN"]))  # development sweep
+if os.environ.get("IPA_SWITCH"): ctx.set_ipa_switch(1 << int(os.environ["IPA_SWITCH"]))  # key size at which the IPA stops folding (log2)
 if os.environ.get("FOLD_TABLE"): ctx.set_fold_table(int(os.environ["FOLD_TABLE"]))     # -1 default, 0 never, 1 at the first open
 _d = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
 ctx.rng_scalars_dev(3, n + 2, _d.data_ptr())
