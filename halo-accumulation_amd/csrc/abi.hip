@@ -1375,8 +1375,14 @@ size_t halo_ctx_info(const halo_ctx *ctx, int what) {
     if (what == 2) return (size_t)(ctx->foldtab_build_ms * 1e3);
     if (what == 3 || what == 4) {
         std::lock_guard<std::mutex> lk(g_budget_mu);
-        (void)hipSetDevice(ctx->device);
-        DeviceBudget &b = budget_of(ctx->device);
+        DeviceBudget &b = g_budget[ctx->device & 63];
+        if (!b.known) {  // (the default is a fraction of THIS device's memory: asked once, the caller's current device is put back)
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            (void)hipSetDevice(ctx->device);
+            (void)budget_of(ctx->device);
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
         return what == 3 ? b.budget : b.used;
     }
     if (what == 5) return ctx->fold_table_mode == 0 ? 5 : ctx->d_foldtab ? 2 : (size_t)ctx->foldtab_status;
