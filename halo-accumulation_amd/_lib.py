@@ -45,6 +45,7 @@ _SIGS = {
     "halo_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_create_urs_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]),
     "halo_ctx_devices": (C.c_int, [C.c_void_p]),
+    "halo_ctx_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "halo_ctx_destroy": (None, [C.c_void_p]),
     "halo_ctx_size": (C.c_size_t, [C.c_void_p]),
     "halo_ctx_read_bases": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, u64p]),
@@ -216,6 +217,14 @@ class Context:
         self.lib = lib
         self.device = device
         self._children = []  # weak references to the Ipa states of this context: they must go before it
+
+    def clone(self):
+        """a second context over the same resident key and tables (halo_ctx_clone): one per host thread"""
+        h = C.c_void_p()
+        check(self.lib.halo_ctx_clone(self.h, C.byref(h)))
+        other = Context.__new__(Context)
+        other.h, other.lib, other.device, other._children = h, self.lib, self.device, []
+        return other
 
     def close(self):
         if getattr(self, "h", None):

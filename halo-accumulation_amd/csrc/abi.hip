@@ -66,7 +66,11 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     alloc_epoch_bump(ctx);
     for (int k = 0; k < HALO_SLOTS; ++k) HALO_HIP(hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
     ctx->stream = ctx->streams[0];
-    HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 128));
+    if (!ctx->share) {  // (a clone arrives with the key it shares: halo_ctx_clone)
+        HALO_HIP(hipMalloc(&ctx->d_bases, (n ? n : 1) * 128));
+        ctx->share = std::make_shared<KeyShare>();
+        ctx->share->d_bases = ctx->d_bases;
+    }
     size_t tn = n < 64 ? 64 : n;
     ctx->tmp_words = tn * 12;
     HALO_HIP(hipMalloc(&ctx->d_tmp_a, tn * 12 * 8));
@@ -289,6 +293,28 @@ int halo_ctx_create_urs_multi(const int *devices, int n_dev, uint64_t first_inde
 }
 int halo_ctx_devices(const halo_ctx *ctx) { return ctx ? (ctx->shards.empty() ? 1 : (int)ctx->shards.size()) : 0; }
 
+// A second context over the SAME resident key (one per host thread: contexts are independent, calls on one context must not
+// overlap).  It shares the key and -- as they come into being, whoever builds them -- the fixed-base MSM table and the fold
+// table, and owns its streams, workspaces, scratch and IPA buffers (~2.3 GB at 2^20 points against 37 GB for a context of its
+// own with both tables).  Tuning knobs are copied from `ctx` at this moment and independent afterwards.
+int halo_ctx_clone(halo_ctx *src, halo_ctx **out) {
+    if (!src || !out) { set_error("ctx_clone: null argument"); return HALO_E_ARG; }
+    if (!src->shards.empty() || src->parent) { set_error("ctx_clone: multi-device contexts and their shards are not cloned"); return HALO_E_ARG; }
+    halo_ctx *ctx = new (std::nothrow) halo_ctx();
+    if (!ctx) { set_error("out of host memory"); return HALO_E_ARG; }
+    ctx->share = src->share;
+    { std::lock_guard<std::mutex> lk(ctx->share->mu); ctx->share->users++; }
+    ctx->d_bases = ctx->share->d_bases;
+    int rc = ctx_alloc_common(ctx, src->device, src->n);
+    if (rc != HALO_OK) { halo_ctx_destroy(ctx); return rc; }
+    ctx->window_bits = src->window_bits; ctx->reduce_span = src->reduce_span; ctx->sort_two_level = src->sort_two_level;
+    ctx->task_len = src->task_len; ctx->table_mode = src->table_mode; ctx->small_path = src->small_path; ctx->use_graphs = src->use_graphs;
+    ctx->nofold_size = src->nofold_size; ctx->batch_verify = src->batch_verify; ctx->fold_table_mode = src->fold_table_mode;
+    ctx->fold_levels = src->fold_levels; ctx->fold_async = src->fold_async;
+    *out = ctx;
+    return HALO_OK;
+}
+
 void halo_ctx_destroy(halo_ctx *ctx) {
     if (!ctx) return;
     multi_destroy(ctx);
@@ -300,7 +326,19 @@ void halo_ctx_destroy(halo_ctx *ctx) {
     msm_workspace_free(ctx);
     foldtab_release(ctx);
     ipa_bufs_release(ctx);
-    (void)hipFree(ctx->d_bases);
+    if (ctx->share) {  // the key itself: freed by its last user (the tables went above, the same way)
+        bool last;
+        { std::lock_guard<std::mutex> lk(ctx->share->mu); last = --ctx->share->users == 0; }
+        if (last) {  // (tables a user had given up while others still held them went nowhere: they go now)
+            (void)hipFree(ctx->share->d_table);
+            (void)hipFree(ctx->share->d_foldtab);
+            ctx->share->d_table = ctx->share->d_foldtab = nullptr;
+            table_budget_release(ctx, ctx->share->budget_held);
+            (void)hipFree(ctx->share->d_bases);
+        }
+    } else {
+        (void)hipFree(ctx->d_bases);
+    }
     (void)hipFree(ctx->d_tmp_a);
     (void)hipFree(ctx->d_tmp_b);
     (void)hipFree(ctx->d_tmp_c);
@@ -1341,14 +1379,14 @@ bool table_budget_reserve(halo_ctx *ctx, size_t bytes) {
         return false;
     }
     b.used += bytes;
-    ctx->budget_held += bytes;
+    ctx->share->budget_held += bytes;  // (on the books of the key: a clone may outlive the context that built a table)
     return true;
 }
 void table_budget_release(halo_ctx *ctx, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_budget_mu);
     DeviceBudget &b = g_budget[ctx->device & 63];
-    if (bytes > ctx->budget_held) bytes = ctx->budget_held;
-    ctx->budget_held -= bytes;
+    if (bytes > ctx->share->budget_held) bytes = ctx->share->budget_held;
+    ctx->share->budget_held -= bytes;
     b.used = b.used >= bytes ? b.used - bytes : 0;
 }
 }  // namespace halo

@@ -223,15 +223,45 @@ static size_t foldtab_slice(size_t cnt) { return cnt < ((size_t)1 << 15) ? cnt :
 static size_t foldtab_table_bytes(size_t n) { return (size_t)FT_ENTRIES * (n - n / 4) * FT_WORDS * 4; }
 static size_t foldtab_tmp_bytes(size_t n) { return (size_t)FT_ENTRIES * foldtab_slice(n - n / 4) * FT_TMP_WORDS * 4; }
 
+// this context stops using the table; the memory goes back unless a clone (halo_ctx_clone) still uses the key
 void foldtab_release(halo_ctx *ctx) {
     foldtab_cancel_alloc(ctx);
     if (!ctx->d_foldtab) return;
     alloc_epoch_bump(ctx);
-    (void)hipFree(ctx->d_foldtab);
-    table_budget_release(ctx, ctx->foldtab_bytes);
+    bool free_it = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->share->mu);
+        if (ctx->share->users == 1 && ctx->share->d_foldtab == ctx->d_foldtab) { ctx->share->d_foldtab = nullptr; ctx->share->foldtab_bytes = 0; free_it = true; }
+    }
+    if (free_it) {
+        (void)hipFree(ctx->d_foldtab);
+        table_budget_release(ctx, ctx->foldtab_bytes);
+    }
     ctx->d_foldtab = nullptr;
     ctx->foldtab_bytes = 0;
     ctx->foldtab_status = 0;
+}
+// a clone has built the table meanwhile?  Take it.  (true = this context now has the table)
+static bool foldtab_adopt(halo_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->share->mu);
+    if (!ctx->share->d_foldtab) return false;
+    alloc_epoch_bump(ctx);
+    ctx->d_foldtab = ctx->share->d_foldtab;
+    ctx->foldtab_bytes = ctx->share->foldtab_bytes;
+    ctx->foldtab_build_ms = ctx->share->foldtab_build_ms;
+    ctx->foldtab_status = 2;
+    return true;
+}
+// one context at a time requests / builds the table of a key; the others take the generic kernel until it is published
+static bool foldtab_claim(halo_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->share->mu);
+    if (ctx->share->foldtab_busy || ctx->share->d_foldtab) return false;
+    ctx->share->foldtab_busy = true;
+    return true;
+}
+static void foldtab_unclaim(halo_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->share->mu);
+    ctx->share->foldtab_busy = false;
 }
 
 // the table over [n/4, n) of the context's key, built in slices through a temporary of at most ~4 GiB
@@ -264,7 +294,7 @@ void foldtab_cancel_alloc(halo_ctx *ctx) {
     if (ctx->foldtab_pending) (void)hipFree(ctx->foldtab_pending);
     if (ctx->foldtab_pending_tmp) (void)hipFree(ctx->foldtab_pending_tmp);
     ctx->foldtab_pending = ctx->foldtab_pending_tmp = nullptr;
-    if (had) foldtab_unreserve(ctx, false);
+    if (had) { foldtab_unreserve(ctx, false); foldtab_unclaim(ctx); }
     ctx->foldtab_alloc_state = 0;
     if (ctx->foldtab_status == 1) ctx->foldtab_status = 0;
 }
@@ -296,6 +326,7 @@ static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp =
         (void)hipGetLastError();
         if (tab) (void)hipFree(tab);
         foldtab_unreserve(ctx, false);
+        foldtab_unclaim(ctx);
         foldtab_later(ctx, 4, hipGetErrorString(e));  // this context carries on with the generic fold
         return HALO_OK;
     }
@@ -305,6 +336,13 @@ static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp =
     ctx->foldtab_bytes = bytes;
     ctx->foldtab_status = 2;
     ctx->foldtab_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    {   // published: clones of this context adopt it at their next full-size open
+        std::lock_guard<std::mutex> lk(ctx->share->mu);
+        ctx->share->d_foldtab = tab;
+        ctx->share->foldtab_bytes = bytes;
+        ctx->share->foldtab_build_ms = ctx->foldtab_build_ms;
+        ctx->share->foldtab_busy = false;
+    }
     if (debug_trace())
         fprintf(stderr, "[halo] fold table ctx=%p [%p, +%zu) built in %.1f ms (%.1f ms of it the two allocations)\n", (void *)ctx, (void *)tab, bytes,
                 ctx->foldtab_build_ms, alloc_ms);
@@ -315,6 +353,7 @@ static int foldtab_build(halo_ctx *ctx, uint32_t *tab = nullptr, uint32_t *tmp =
 // ran, 0 if the caller should take the generic kernel, < 0 on a launch error.
 int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size_t m, const host::Fr s[3]) {
     if (d_src != ctx->d_bases || 4 * m != ctx->n || m < 16 || d_dst == d_src || ctx->fold_table_mode == 0) return 0;
+    if (!ctx->d_foldtab) (void)foldtab_adopt(ctx);
     if (!ctx->d_foldtab) {
         // mode 1: at the first full-size open; default (-1): the memory is requested on a helper thread at the first full-size
         // open and the table is built at the first later open that finds it there (a context that opens once never waits)
@@ -336,7 +375,8 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
             }
             if (!reserved) {
                 if (ctx->foldtab_opens < ctx->foldtab_retry_at) return 0;
-                if (!foldtab_reserve(ctx)) { foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
+                if (!foldtab_claim(ctx)) return 0;  // (a clone is at it: the generic kernel this time)
+                if (!foldtab_reserve(ctx)) { foldtab_unclaim(ctx); foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
             }
             rc = foldtab_build(ctx, tab, tmp);
         } else {
@@ -344,7 +384,8 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
             int st = ctx->foldtab_alloc_state.load(std::memory_order_acquire);
             if (st == 0) {  // first full-size open: ask for the memory in the background; this open takes the generic kernel
                 if (ctx->foldtab_opens < ctx->foldtab_retry_at) return 0;
-                if (!foldtab_reserve(ctx)) { foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
+                if (!foldtab_claim(ctx)) return 0;  // (a clone is at it: the generic kernel this time)
+                if (!foldtab_reserve(ctx)) { foldtab_unclaim(ctx); foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }
                 ctx->foldtab_alloc_state = 1;
                 ctx->foldtab_status = 1;
                 ctx->foldtab_alloc_thread = std::thread([ctx] {

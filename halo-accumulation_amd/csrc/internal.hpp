@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -232,8 +233,27 @@ struct IpaBuffers {
     bool in_use = false;
 };
 
+// What the contexts over ONE resident key have in common (halo_ctx_clone): the key, its fixed-base MSM table and its fold
+// table -- immutable once built -- and the optional-memory bytes they hold on the device's books.  Every context owns a
+// reference (a context that was never cloned is the only user of its own); the last one to go frees the memory.  `mu` guards
+// the fields; a table is built by ONE context at a time (`*_busy`), the others run table-free meanwhile and adopt it at their
+// next opportunity.
+struct KeyShare {
+    std::mutex mu;
+    int users = 1;
+    uint32_t *d_bases = nullptr;
+    uint32_t *d_table = nullptr;
+    halo::TblPlan tbl{};
+    uint32_t *d_foldtab = nullptr;
+    size_t foldtab_bytes = 0;
+    double foldtab_build_ms = 0;
+    bool table_busy = false, foldtab_busy = false;
+    size_t budget_held = 0;  // bytes of optional memory reserved for this key (abi.hip table_budget_*)
+};
+
 struct halo_ctx {
     int device = 0;
+    std::shared_ptr<KeyShare> share;  // d_bases / d_table / d_foldtab below are this context's view of it
     hipStream_t stream = nullptr;      // stream the launch macro uses (= streams[slot in use])
     hipStream_t streams[HALO_SLOTS] = {};
     size_t n = 0;
@@ -264,7 +284,7 @@ struct halo_ctx {
     long table_calls = 0, table_retry_at = 0, table_backoff = 64;
     int table_status = 0;
     bool table_said = false, foldtab_said = false;  // the one line on stderr has been printed
-    size_t budget_held = 0;                // optional table memory this context holds against its device's budget (abi.hip)
+    // (the optional-memory bytes are on the books of the key: share->budget_held)
     // automatic mode: the table's 40 GB are requested on a helper thread at the first full-size open (hipMalloc of that size
     // takes 0.5 ms .. 2 s depending on what the driver has at hand) and the table is built at the first later open that
     // finds them there.  state: 0 nothing, 1 running, 2 ready, 3 failed
@@ -351,7 +371,8 @@ struct BorrowScope {
 inline void alloc_epoch_bump(halo_ctx *ctx) { ctx->alloc_epoch++; }
 int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot);
 void msm_workspace_free(halo_ctx *ctx);
-int table_release(halo_ctx *ctx);  // frees the context's fixed-base table (every slot idle)
+int table_release(halo_ctx *ctx);  // gives up the context's fixed-base table (every slot idle): freed unless a clone still uses it
+void table_detach(halo_ctx *ctx);   // the same without the idle check (context teardown)
 // asynchronous halves of msm_run on workspace/stream `slot`
 int msm_enqueue(halo_ctx *ctx, int slot, const uint32_t *d_bases, const uint64_t *d_scalars, bool scalars_mont, size_t n);
 int msm_finish(halo_ctx *ctx, int slot, host::Point *out);

@@ -1583,9 +1583,7 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
 }
 void msm_workspace_free(halo_ctx *ctx) {
     alloc_epoch_bump(ctx);
-    if (ctx->d_table) table_budget_release(ctx, (size_t)ctx->tbl.W * ctx->n * 128);
-    (void)hipFree(ctx->d_table);
-    ctx->d_table = nullptr;
+    table_detach(ctx);
     for (int slot = 0; slot < HALO_SLOTS; ++slot) workspace_release(ctx->wss[slot]);
 }
 
@@ -1763,7 +1761,21 @@ static int table_build(halo_ctx *ctx) {
     if (ctx->d_table) return HALO_OK;
     // a table that could not be had is tried again after table_backoff more eligible MSMs (64, 128, ... 4096), not never:
     // the memory may have come back, the budget may have been raised
-    if (++ctx->table_calls < ctx->table_retry_at) return HALO_OK;
+    {   // a clone of this context (halo_ctx_clone) may have built the table already, or be building it right now
+        std::lock_guard<std::mutex> lk(ctx->share->mu);
+        if (ctx->share->d_table) {
+            alloc_epoch_bump(ctx);
+            ctx->tbl = ctx->share->tbl;
+            ctx->d_table = ctx->share->d_table;
+            ctx->table_status = 2;
+            return HALO_OK;
+        }
+        if (ctx->share->table_busy) return HALO_OK;  // (this MSM takes the table-free pipeline; the next one looks again)
+        if (ctx->table_calls + 1 < ctx->table_retry_at) { ++ctx->table_calls; return HALO_OK; }
+        ctx->share->table_busy = true;
+    }
+    struct Busy { KeyShare *k; ~Busy() { std::lock_guard<std::mutex> lk(k->mu); k->table_busy = false; } } busy{ctx->share.get()};
+    ++ctx->table_calls;
     size_t n = ctx->n;
     TblPlan tp = table_plan(n);
     const size_t bytes = (size_t)tp.W * n * 128;
@@ -1800,6 +1812,11 @@ static int table_build(halo_ctx *ctx) {
         later(4, hipGetErrorString(e));
         return HALO_OK;
     }
+    {
+        std::lock_guard<std::mutex> lk(ctx->share->mu);
+        ctx->share->tbl = tp;
+        ctx->share->d_table = tbl;
+    }
     ctx->tbl = tp;
     ctx->d_table = tbl;
     ctx->table_status = 2;
@@ -1813,11 +1830,24 @@ int table_release(halo_ctx *ctx) {
         HALO_HIP(hipStreamSynchronize(ctx->streams[k]));
     }
     alloc_epoch_bump(ctx);  // cached launch graphs name the table
-    (void)hipFree(ctx->d_table);
-    table_budget_release(ctx, (size_t)ctx->tbl.W * ctx->n * 128);
+    table_detach(ctx);
+    return HALO_OK;
+}
+// this context stops using the table; the memory goes back when no clone uses it either (each user's view is its own d_table:
+// a user that still holds one is counted by looking at the share's other users -- conservatively: freed by the last user of the key)
+void table_detach(halo_ctx *ctx) {
+    if (!ctx->d_table) return;
+    bool free_it = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->share->mu);
+        if (ctx->share->users == 1 && ctx->share->d_table == ctx->d_table) { ctx->share->d_table = nullptr; ctx->share->tbl = TblPlan{}; free_it = true; }
+    }
+    if (free_it) {
+        (void)hipFree(ctx->d_table);
+        table_budget_release(ctx, (size_t)ctx->tbl.W * ctx->n * 128);
+    }
     ctx->d_table = nullptr;
     ctx->tbl = TblPlan{};
-    return HALO_OK;
 }
 // can this launch take the table pipeline?  One MSM, all windows, over a stretch of the context's own key -- of at least 2^20
 // points, or at least half of a smaller key (that plan's coarse ranges are sized for the key) -- indices within 31 bits.

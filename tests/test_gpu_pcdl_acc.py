@@ -975,6 +975,82 @@ def test_memory_budget_bounds_the_optional_tables_of_all_contexts_on_a_device(ha
         b.close()
 
 
+def test_clones_share_the_key_and_its_tables(hal):
+    """halo_ctx_clone: contexts over ONE resident key.  The clone gives the same points and proofs; the tables exist once
+    (the device's optional-memory books do not move when the clone uses them, whoever built them); two threads open at the
+    same time on the two contexts; the original may go first -- the clone keeps working and the last one frees everything."""
+    import threading
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 18
+    d = n - 1
+    ft, msm_tab = 704 * 64 * (n - n // 4), 15 * 128 * n
+    a = hal._lib.Context(urs_n=n)
+    used0 = a.info(4)
+    free0 = torch.cuda.mem_get_info()[0]
+    b = a.clone()
+    try:
+        assert b.size == n and b.read_bases(5, 3).tolist() == a.read_bases(5, 3).tolist()
+        dv = torch.empty((n + 1) * 4, dtype=torch.int64, device="cuda")
+        a.rng_scalars_dev(0xC10E, n + 1, dv.data_ptr())
+        z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
+        # the CLONE builds the MSM table (first commit) and the fold table (first open, mode 1); the original adopts both
+        b.set_fold_table(1); a.set_fold_table(1)
+        Cb = pcdl.commit_dev(b, dv.data_ptr(), n, d)
+        pb = pcdl.open_dev(b, [1], dv.data_ptr(), n, Cb, d, z)
+        assert b.info(0) == msm_tab and b.info(1) == ft and a.info(4) == used0 + ft + msm_tab
+        Ca = pcdl.commit_dev(a, dv.data_ptr(), n, d)
+        pa = pcdl.open_dev(a, [1], dv.data_ptr(), n, Ca, d, z)
+        assert Ca.tolist() == Cb.tolist() and pa.tolist() == pb.tolist()
+        assert a.info(0) == msm_tab and a.info(1) == ft and a.info(2) == b.info(2), "adopted, not built again"
+        assert a.info(4) == used0 + ft + msm_tab, "one copy of each table on the device's books"
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] < ft + msm_tab + (3 << 30), "the clone costs workspaces and IPA buffers, not a second set of tables"
+        v = a.poly_eval(np.ascontiguousarray(dv[: 4 * n].cpu().numpy().view(np.uint64).reshape(n, 4)), z)
+        # both at once, one thread each
+        out, errs = {}, []
+
+        def work(c, key):
+            try:
+                for _ in range(3):
+                    p = pcdl.open_dev(c, [1], dv.data_ptr(), n, Ca, d, z)
+                    pcdl.check_proof(c, Ca, d, z, v, p)
+                out[key] = p.tolist()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        ths = [threading.Thread(target=work, args=(c, k)) for c, k in ((a, "a"), (b, "b"))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs and out["a"] == out["b"] == pa.tolist()
+        # one context gives up the fold table: the other keeps it, nothing is freed
+        a.set_fold_table(0)
+        assert a.info(1) == 0 and b.info(1) == ft and a.info(4) == used0 + ft + msm_tab
+        assert pcdl.open_dev(a, [1], dv.data_ptr(), n, Ca, d, z).tolist() == pa.tolist()  # generic fold, same proof
+        # the original goes first
+        a.close()
+        assert pcdl.open_dev(b, [1], dv.data_ptr(), n, Cb, d, z).tolist() == pb.tolist()
+        assert b.msm_dev(dv.data_ptr(), n).tolist() == Cb.tolist()
+        assert b.info(4) == used0 + ft + msm_tab
+        c3 = b.clone()  # a clone of the clone, after the original is gone
+        assert c3.msm_dev(dv.data_ptr(), n).tolist() == Cb.tolist() and c3.info(0) == msm_tab
+        c3.close()
+        used_probe = b.info(4)
+        b.close()
+        probe = hal._lib.Context(urs_n=64)
+        assert used_probe == used0 + ft + msm_tab and probe.info(4) == used0, "the last context over the key frees the tables"
+        probe.close()
+    finally:
+        a.close()
+        b.close()
+    multi = hal._lib.Context(urs_n=1 << 12, devices=[0, 0])
+    with pytest.raises(hal._lib.HaloError):
+        multi.clone()
+    multi.close()
+
+
 def test_memory_budget_from_the_environment():
     """HALO_MEMORY_BUDGET replaces the default budget for the whole process (for hosts that cannot call the setter: the Rust
     shim); 0 = no optional memory: the table-free pipeline, same point as the oracle's."""
