@@ -661,6 +661,52 @@ def main():
             result["asdl_chain"] = {"steps": args.asdl_steps, "n": n, "instance_plus_prover_ms_each": t_c * 1e3,
                                     "verifier_ms_each": t_v * 1e3, "decider_ms": t_d * 1e3, "all_accepted": True,
                                     "fold_table_in_place": ctx.info(1) > 0}
+            if args.concurrent_opens > 1:
+                # The same chain with the work of a step on TWO host threads: random_instance for step k + 1 (one hiding open) on a
+                # clone of the context while acc::prover of step k (the other hiding open) runs on the context itself -- the two
+                # are independent (benches/acc.rs:76-98 runs them one after the other on one thread).  Each thread has its own
+                # SplitMix64 stream, so the accumulators differ from the sequential chain's; every one is verified and the last decided.
+                import threading
+                K = args.asdl_steps
+                cl = ctx.clone()
+                insts, ready = [None] * K, [threading.Event() for _ in range(K)]
+                errs2 = []
+
+                def gen():
+                    try:
+                        torch.cuda.set_device(gpu)
+                        rng_g = [0x48414C4F00000014]
+                        for k in range(K):
+                            insts[k] = A.random_instance(cl, rng_g, n - 1)
+                            ready[k].set()
+                    except Exception as e:  # noqa: BLE001
+                        errs2.append(repr(e))
+                        for ev in ready:
+                            ev.set()
+
+                accs2, qss2, acc2 = [], [], None
+                rng_p = [0x48414C4F00000024]
+                A.random_instance(cl, [1], n - 1)  # (the clone's first open allocates its IPA buffers: untimed)
+                tg = threading.Thread(target=gen)
+                t0 = time.perf_counter()
+                tg.start()
+                for k in range(K):
+                    ready[k].wait()
+                    if errs2:
+                        break
+                    qs = [insts[k]] if acc2 is None else [A.instance_from_accumulator(ctx, acc2, n - 1), insts[k]]
+                    acc2 = A.prover(ctx, rng_p, n - 1, qs)
+                    accs2.append(acc2); qss2.append(qs)
+                tg.join()
+                t_pipe = (time.perf_counter() - t0) / K
+                assert not errs2, errs2
+                for a_, qs in zip(accs2, qss2):
+                    A.verifier(ctx, n - 1, qs, a_)
+                A.decider(ctx, accs2[-1])
+                cl.close()
+                result["asdl_chain"]["two_threads"] = {"instance_plus_prover_ms_each": t_pipe * 1e3, "steps": K, "all_accepted": True,
+                                                       "note": "random_instance of step k + 1 on a clone of the context (halo_ctx_clone) while acc::prover of step k "
+                                                               "runs on the context: one resident key and one set of tables, two host threads"}
             if ctx_small is not None:
                 ks = max(2, min(args.asdl_steps, 2))
                 chain(ctx_small, small_n - 1, 1, 0x48414C4F00000004)  # warm-up: buffers, launch graphs

@@ -45,6 +45,7 @@ def test_bench_emits_contract_json():
     assert ocb["kind"] == "port" and ocb["cores"] == 1 and ocb["value"] > 0 and ocb["proof_bit_exact"] is True and ocb["gpu_same_n"]["value"] > 0
     assert ocb["unit"] == "open+check/s" and "sample" in ocb and "-march=native" in ocb["build"] and "-march=x86-64-v2" in ocb["build"]
     assert oc["in_flight"]["pairs_in_flight"] == 2 and oc["in_flight"]["value"] > 0 and oc["in_flight"]["optional_memory_added_by_the_clones_bytes"] == 0
+    assert r["asdl_chain"]["two_threads"]["all_accepted"] is True and r["asdl_chain"]["two_threads"]["instance_plus_prover_ms_each"] > 0
     acb = r["asdl_chain"]["cpu_baseline"]
     assert acb["kind"] == "port" and acb["cores"] == 1 and acb["value"] > 0 and acb["accumulators_bit_exact"] is True
     assert acb["gpu_same_n"]["instance_plus_prover_ms_each"] > 0 and acb["decider_ms"] > 0
