@@ -70,7 +70,7 @@ int halo_ctx_devices(const halo_ctx *ctx); /* shards of a multi-device context, 
  * table and the fold table (immutable, reference-counted: freed with the last context over the key), and owns its streams,
  * workspaces, scratch and IPA buffers: ~2.3 GB at 2^20 points instead of the 37 GB of an independent context with both
  * tables.  Contexts over one key are as independent as any two contexts: calls on ONE context must not overlap, calls on
- * different ones may (two open + check pairs in flight on two clones: 13.6 ms per pair against 16.9 ms one at a time).  The
+ * different ones may (two open + check pairs in flight on a context and its clone: ~14 ms per pair against ~17 ms one at a time).  The
  * tuning knobs are copied at this moment.  Not for multi-device contexts.  halo_set_table_mode(ctx, 0) /
  * halo_set_fold_table(ctx, 0) on one of them stop THAT context's use of the table; the memory goes back when no context
  * over the key is left to use it. */
