@@ -90,6 +90,7 @@ struct MsmBatch {
     const uint64_t *scalars[MSM_MAX_BATCH] = {};
     uint32_t base_off[MSM_MAX_BATCH] = {};
     int part = 0, parts = 1;  // window shard: this launch computes windows [part*W/parts, (part+1)*W/parts)
+    int c_hint = 0;           // window bits the caller knows to be better for THIS launch's scalars (0: the size-based table); halo_set_window_bits wins
 };
 MsmPlan msm_plan(size_t n, int forced_c);
 uint32_t msm_spread(const MsmPlan &p, uint32_t *top_bit);  // top-window spread of the recode (0: none)
@@ -123,7 +124,7 @@ struct MsmWorkspace {
         int mont = 0, c = 0, span = 0;
         bool operator==(const GraphKey &o) const {
             if (!(bases == o.bases && n == o.n && mont == o.mont && c == o.c && span == o.span && members.count == o.members.count &&
-                  members.part == o.members.part && members.parts == o.members.parts))
+                  members.part == o.members.part && members.parts == o.members.parts && members.c_hint == o.members.c_hint))
                 return false;
             for (int b = 0; b < members.count; ++b)
                 if (members.scalars[b] != o.members.scalars[b] || members.base_off[b] != o.members.base_off[b]) return false;

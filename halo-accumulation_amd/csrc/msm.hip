@@ -1619,8 +1619,10 @@ static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) {
 }
 
 // what a batch of `count` MSMs of n points needs beyond the slot's current capacity (0 = fits)
-static bool batch_need(const halo_ctx *ctx, const MsmWorkspace &ws, size_t n, int count, WorkspaceNeed &need) {
-    MsmPlan p = msm_plan(n, ctx->window_bits);
+// window bits of a launch: the context's forced value, else the caller's hint for these scalars, else the size-based table
+static int launch_c(const halo_ctx *ctx, const MsmBatch &members) { return ctx->window_bits > 0 ? ctx->window_bits : members.c_hint; }
+static bool batch_need(const halo_ctx *ctx, const MsmWorkspace &ws, size_t n, int count, WorkspaceNeed &need, int c_hint) {
+    MsmPlan p = msm_plan(n, ctx->window_bits > 0 ? ctx->window_bits : c_hint);
     size_t Wt = (size_t)p.W * count, total = Wt * p.B, sorted = n * Wt;
     if (count > 1 && ctx->n < ((size_t)1 << 20) && ctx->n >= ((size_t)1 << 17)) {  // room for a batch through the small-key table plan
         size_t sets = 1;
@@ -1662,20 +1664,20 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     if (members.parts < 1 || members.part < 0 || members.part >= members.parts) { set_error("msm: window shard out of range"); return HALO_E_ARG; }
     if (n == 0) { ws.in_flight = true; return HALO_OK; }
     if (members.parts > 1) {  // a shard that owns no window (more shards than windows) contributes the point at infinity
-        MsmPlan p = msm_plan(n, ctx->window_bits);
+        MsmPlan p = msm_plan(n, launch_c(ctx, members));
         if (p.W * members.part / members.parts == p.W * (members.part + 1) / members.parts) { ws.in_flight = true; return HALO_OK; }
     }
     {
         // A batch lays the members' windows side by side and a forced task length multiplies the tasks: grow
         // this slot's workspace when the launch needs more room than a single automatic-plan MSM of the
         // context's size (the slot is idle here and its stream is drained).
-        MsmPlan p = msm_plan(n, ctx->window_bits);
+        MsmPlan p = msm_plan(n, launch_c(ctx, members));
         if ((size_t)p.W * members.count * p.B > ((size_t)1 << 22)) {
             set_error("msm: batch too large for this window size (windows * batch * buckets <= 2^22)");
             return HALO_E_ARG;
         }
         WorkspaceNeed need;
-        if ((members.count > 1 || ctx->task_len > 0) && batch_need(ctx, ws, n, members.count, need)) {
+        if ((members.count > 1 || ctx->task_len > 0) && batch_need(ctx, ws, n, members.count, need, members.c_hint)) {
             alloc_epoch_bump(ctx);
             workspace_release(ws);
             int rc = workspace_alloc(ws, need);
@@ -2015,7 +2017,7 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
 int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, bool mont, size_t n, int partner) {
     if (n > ws.cap_n) { set_error("msm: n exceeds the context's workspace"); return HALO_E_ARG; }
     if (ctx->d_table && table_eligible(ctx, d_bases, members, n)) return tmsm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
-    MsmPlan p = msm_plan(n, ctx->window_bits);
+    MsmPlan p = msm_plan(n, launch_c(ctx, members));
     p.batch = members.count;
     p.w0 = p.W * members.part / members.parts;
     p.w1 = p.W * (members.part + 1) / members.parts;
