@@ -741,7 +741,11 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     // for everything queued on stream 0 (the previous round's folds)
     // (a batched round -- see below -- does not use stream 1, and every API call here is GPU idle time in the late rounds:
     // leaving out its two waits and the second event record shortened an open by 0.3 ms)
-    const bool will_batch = st->nofold && st->M < ((size_t)1 << 20);
+    // Over the full key with its c = 20 table in place L and R are ONE launch sequence too, of another kind: their non-zero scalars
+    // sit on disjoint points, so one array with a set bit per element feeds two bucket sets (MsmBatch::tagged) -- one recode, one
+    // sort, one bucket kernel of 13 n additions instead of two of 13 n / 2, one window-sum pass of 2048 waves instead of two of 1024.
+    const bool tagged = st->nofold && st->M >= ((size_t)1 << 20) && msm_tagged_ready(ctx, st->G_src, st->M);
+    const bool will_batch = (st->nofold && st->M < ((size_t)1 << 20)) || tagged;
     HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
     if (!will_batch) HALO_HIP(hipStreamWaitEvent(ctx->streams[1], st->ev, 0));
     HALO_HIP(hipStreamWaitEvent(ctx->streams[2], st->ev, 0));
@@ -766,7 +770,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     st->last_valid = false;
     if (last_round) HALO_HIP(hipMemcpyAsync(ctx->h_pinned + 208, st->d_c, 64, hipMemcpyDeviceToHost, ctx->streams[0]));
     if (st->nofold) {
-        rc = nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
+        rc = tagged ? nofold_expand_tagged(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL) : nofold_expand(ctx, st->d_c, st->d_s, st->m, st->M, st->d_FL, st->d_FR);
         if (rc) return rc;
         if (!will_batch) {
             HALO_HIP(hipEventRecord(st->ev, ctx->streams[0]));
@@ -776,7 +780,14 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
         // launch sequences on two streams did not overlap -- the second one's 1024-thread sort blocks cannot start on a CU
         // that still holds waves of the first one's bucket kernel -- so a round took two MSM latencies instead of one.
         batched = will_batch;
-        if (batched) {
+        if (tagged) {
+            MsmBatch both;
+            both.count = 1;
+            both.scalars[0] = st->d_FL;
+            both.tagged = true;
+            rc = msm_enqueue_batch(ctx, 0, st->G_src, both, false, st->M);
+            if (rc) return rc;
+        } else if (batched) {
             MsmBatch both;
             both.count = 2;
             both.scalars[0] = st->d_FL;

@@ -91,7 +91,12 @@ struct MsmBatch {
     uint32_t base_off[MSM_MAX_BATCH] = {};
     int part = 0, parts = 1;  // window shard: this launch computes windows [part*W/parts, (part+1)*W/parts)
     int c_hint = 0;           // window bits the caller knows to be better for THIS launch's scalars (0: the size-based table); halo_set_window_bits wins
+    // TWO sums from ONE scalar array (count = 1, canonical form, c = 20 table plan only: msm_tagged_ready): bit 255 of scalar i --
+    // free, r < 2^255 -- says which of two bucket sets point i goes to.  One recode / sort / bucket kernel / window-sum pass for
+    // both; results as for a batch of two (msm_wait(.., 2), msm_combine_member 0 / 1).  The IPA's L and R over the full key.
+    bool tagged = false;
 };
+inline int msm_outputs(const MsmBatch &m) { return m.tagged ? 2 : m.count; }
 MsmPlan msm_plan(size_t n, int forced_c);
 uint32_t msm_spread(const MsmPlan &p, uint32_t *top_bit);  // top-window spread of the recode (0: none)
 
@@ -124,17 +129,23 @@ struct MsmWorkspace {
         int mont = 0, c = 0, span = 0;
         bool operator==(const GraphKey &o) const {
             if (!(bases == o.bases && n == o.n && mont == o.mont && c == o.c && span == o.span && members.count == o.members.count &&
-                  members.part == o.members.part && members.parts == o.members.parts && members.c_hint == o.members.c_hint))
+                  members.part == o.members.part && members.parts == o.members.parts && members.c_hint == o.members.c_hint && members.tagged == o.members.tagged))
                 return false;
             for (int b = 0; b < members.count; ++b)
                 if (members.scalars[b] != o.members.scalars[b] || members.base_off[b] != o.members.base_off[b]) return false;
             return true;
         }
     };
-    GraphKey seen_key, graph_key;
-    hipGraphExec_t graph_exec = nullptr;
-    uint64_t graph_epoch = 0;  // the context's alloc_epoch when graph_exec was instantiated
-    MsmPlan graph_plan{};
+    // Launch graphs of this slot, by key: an open's rounds come back with the same few keys open after open (the tagged launch of
+    // rounds 0-1, the batches over the 2^18-, 2^16- and 2^14-point keys, the check's MSM), so the slot keeps several -- with ONE
+    // graph a slot re-captured and re-instantiated four of them per open and launched the other four rounds kernel by kernel.
+    static constexpr int GRAPHS = 8, SEEN = 8;
+    struct CachedGraph { GraphKey key; hipGraphExec_t exec = nullptr; MsmPlan plan{}; uint64_t used = 0; };
+    CachedGraph graphs[GRAPHS];
+    GraphKey seen[SEEN];       // keys that have arrived once (plain launches): the second arrival is captured
+    int seen_at = 0;
+    uint64_t graph_epoch = 0;  // the context's alloc_epoch the graphs were instantiated under (all go when it moves)
+    uint64_t graph_clock = 0;  // least recently used goes first
 };
 
 }  // namespace halo
@@ -384,6 +395,7 @@ void msm_combine(halo_ctx *ctx, int slot, host::Point *out, int count);
 void msm_combine_member(halo_ctx *ctx, int slot, int b, host::Point *out);
 // the same for `members.count` MSMs of n points each issued as ONE launch sequence; out[count]
 int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const MsmBatch &members, bool scalars_mont, size_t n);
+bool msm_tagged_ready(const halo_ctx *ctx, const uint32_t *d_bases, size_t n);  // can a `tagged` launch (MsmBatch) over these points run now?
 int msm_finish_batch(halo_ctx *ctx, int slot, host::Point *out, int count);
 // sum scalars[i] * bases[i]; bases affine (device), scalars device; result host Jacobian (un-normalised)
 // bases: native affine table (20 words per point)
@@ -466,6 +478,7 @@ int pbar_stream_dev(halo_ctx *ctx, uint64_t state0, size_t deg, const host::Fr &
                     uint64_t *d_out);
 int bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps);
 int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_L, uint64_t *d_R);
+int nofold_expand_tagged(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_F);  // one array for a tagged launch
 int nofold_s_update(halo_ctx *ctx, const uint64_t *d_s_in, size_t len, const host::Fr &xi, uint64_t *d_s_out);
 
 // ---- abi.hip (device-pointer forms used by pcdl_acc.hip)

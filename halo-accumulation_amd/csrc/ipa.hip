@@ -642,6 +642,19 @@ __global__ __launch_bounds__(256) void k_nofold_expand(const uint64_t *__restric
         fe_store(outL + 4 * (size_t)b, fe_zero());
     }
 }
+// The same two vectors as ONE array for a tagged launch (msm.hip, MsmBatch::tagged): L's and R's non-zero scalars sit on
+// disjoint points, so F[b] = c[(b mod m) +- m/2] * s[b div m] in canonical form with bit 255 (free: r < 2^255) set on R's half
+// says everything -- half the bytes written, and one launch sequence computes both sums.
+__global__ __launch_bounds__(256) void k_nofold_expand_tagged(const uint64_t *__restrict__ c, const uint64_t *__restrict__ sv, uint32_t m,
+                                                              int log2m, uint32_t M, uint64_t *__restrict__ out) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= M) return;
+    uint32_t u = b & (m - 1), t = b >> log2m, h = m >> 1;
+    Fe v = fe_mul<FrCfg>(fe_load(c + 4 * (size_t)(u < h ? u + h : u - h)), fe_load(sv + 4 * (size_t)t));
+    v = fe_from_mont<FrCfg>(v);
+    if (u >= h) v.v[7] |= 0x80000000u;
+    fe_store(out + 4 * (size_t)b, v);
+}
 // s'[2t + u] = s[t] * xi^u : the stride of the implicit key halves (pcdl.rs:218 applied to the representation)
 __global__ __launch_bounds__(256) void k_nofold_s_update(const uint64_t *__restrict__ s_in, uint32_t len, FeArg xi,
                                                          uint64_t *__restrict__ s_out) {
@@ -946,6 +959,14 @@ int nofold_expand(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_
     while (((size_t)1 << log2m) < m) log2m++;
     HALO_LAUNCH(ctx, "k_nofold_expand", k_nofold_expand, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_c, d_s, (uint32_t)m, log2m,
                 (uint32_t)M, d_L, d_R);
+    HALO_HIP(hipGetLastError());
+    return HALO_OK;
+}
+int nofold_expand_tagged(halo_ctx *ctx, const uint64_t *d_c, const uint64_t *d_s, size_t m, size_t M, uint64_t *d_F) {
+    int log2m = 0;
+    while (((size_t)1 << log2m) < m) log2m++;
+    HALO_LAUNCH(ctx, "k_nofold_expand_tagged", k_nofold_expand_tagged, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, d_c, d_s, (uint32_t)m, log2m,
+                (uint32_t)M, d_F);
     HALO_HIP(hipGetLastError());
     return HALO_OK;
 }

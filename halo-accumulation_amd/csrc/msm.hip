@@ -517,7 +517,9 @@ __global__ __launch_bounds__(256) void k_table_step(const uint32_t *__restrict__
 // blockIdx.y = member of a batched launch (small-key plan): its digits go to rows [member W, (member + 1) W) and carry
 // member * B on top of the bucket number, so that every later kernel sees one MSM with count * B buckets.
 struct TblScalars { const uint64_t *p[MSM_MAX_BATCH]; };
-__global__ __launch_bounds__(256) void k_tmsm_recode(TblScalars members, int mont, uint32_t n, TblPlan tp, uint32_t *__restrict__ digits,
+// tagged (MsmBatch::tagged): ONE scalar array, canonical, whose bit 255 picks the bucket set of point i (0 / 1) the way blockIdx.y
+// does for the members of a batch: rows stay W, buckets become 2 B.
+__global__ __launch_bounds__(256) void k_tmsm_recode(TblScalars members, int mont, int tagged, uint32_t n, TblPlan tp, uint32_t *__restrict__ digits,
                                                      uint32_t *__restrict__ meta, uint32_t *__restrict__ zero_b, uint32_t *__restrict__ zero_t) {
     __shared__ uint32_t sw[256 * 9];
     const uint64_t *__restrict__ scalars = members.p[blockIdx.y];
@@ -533,6 +535,8 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(TblScalars members, int mon
 #pragma unroll
     for (int k = 0; k < 8; k++) my[k] = s.v[k];
     my[8] = 0;
+    uint32_t set = blockIdx.y;
+    if (tagged) { set = my[7] >> 31; my[7] &= 0x7fffffffu; }
     uint32_t flip = 0;
     if (tp.fold_top && (my[7] >> 30) != 0) {
         // c = 17: the top window would hold 2^16 (+ carry) = B + 1 for a scalar >= 2^254 -- one value too many.  Such a
@@ -573,13 +577,16 @@ __global__ __launch_bounds__(256) void k_tmsm_recode(TblScalars members, int mon
     uint32_t carry = 0;
     for (int w = 0; w < tp.W; w++) {
         Digit d = next_digit(my, w, tp.c, tp.B, carry);
-        digits[((size_t)blockIdx.y * tp.W + w) * n + i] = d.mag ? ((d.mag - 1 + blockIdx.y * tp.B) | ((d.neg ^ flip) << 31)) : TDIGIT_NONE;
+        digits[((size_t)blockIdx.y * tp.W + w) * n + i] = d.mag ? ((d.mag - 1 + set * tp.B) | ((d.neg ^ flip) << 31)) : TDIGIT_NONE;
     }
 }
 // block (w, chunk): counts of the 512 coarse ranges, one private row per wave
-__global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
-                                                           TblPlan tp, uint32_t *__restrict__ chist) {
-    __shared__ uint32_t cnt[16 * TBL_MAX_RANGES];
+// (MAXR = 1024: the c = 20 plan with TWO bucket sets, a `tagged` launch -- the kernels with a 2 in their names)
+template <uint32_t MAXR>
+HALO_DEV void tmsm_coarse_hist_body(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len, const TblPlan &tp,
+                                    uint32_t *__restrict__ chist) {
+    __shared__ uint32_t cnt[16 * MAXR];
+    constexpr uint32_t TBL_MAX_RANGES = MAXR;
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
     for (uint32_t k = threadIdx.x; k < 16 * TBL_MAX_RANGES; k += 1024) cnt[k] = 0;
     __syncthreads();
@@ -600,6 +607,14 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__res
         chist[(size_t)blockIdx.x * tp.ranges + threadIdx.x] = t;
     }
 }
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_hist(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                           TblPlan tp, uint32_t *__restrict__ chist) {
+    tmsm_coarse_hist_body<TBL_MAX_RANGES>(digits, n, nchunks, chunk_len, tp, chist);
+}
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_hist2(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                            TblPlan tp, uint32_t *__restrict__ chist) {
+    tmsm_coarse_hist_body<2 * TBL_MAX_RANGES>(digits, n, nchunks, chunk_len, tp, chist);
+}
 // chist[chunk][range] -> exclusive prefix over the chunks of each range (in place); rtotal[range] = the range's size.
 // One block per range: 247 counters, loaded once, scanned in LDS.
 __global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__ chist, uint32_t nchunks_all, uint32_t ranges, uint32_t *__restrict__ rtotal) {
@@ -618,8 +633,8 @@ __global__ __launch_bounds__(256) void k_tmsm_scan_chunks(uint32_t *__restrict__
     if (t == 255) rtotal[r] = part[255];
 }
 // cstart[r] = start of run r in the presorted array, cstart[512] = number of entries
-__global__ __launch_bounds__(512) void k_tmsm_scan_ranges(const uint32_t *__restrict__ rtotal, uint32_t *__restrict__ cstart) {
-    __shared__ uint32_t part[TBL_MAX_RANGES];
+__global__ __launch_bounds__(1024) void k_tmsm_scan_ranges(const uint32_t *__restrict__ rtotal, uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t part[2 * TBL_MAX_RANGES];
     const uint32_t ranges = blockDim.x;  // one thread per range
     uint32_t t = threadIdx.x, v = rtotal[t];
     part[t] = v;
@@ -638,10 +653,11 @@ __global__ __launch_bounds__(512) void k_tmsm_scan_ranges(const uint32_t *__rest
 // rewritten), so the block goes through its chunk in tiles of 8192 entries: a tile is grouped by range in LDS (local
 // ranks from an LDS histogram), then written out in that order -- entries of one range land on consecutive addresses.
 constexpr uint32_t TBL_TILE = 8192;
-__global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
-                                                              const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
-                                                              uint32_t table_n, uint32_t base_off, TblPlan tp, uint32_t *__restrict__ presort,
-                                                              uint16_t *__restrict__ presort_fine) {
+template <uint32_t MAXR>
+HALO_DEV void tmsm_coarse_scatter_body(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                       const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart, uint32_t table_n, uint32_t base_off,
+                                       const TblPlan &tp, uint32_t *__restrict__ presort, uint16_t *__restrict__ presort_fine) {
+    constexpr uint32_t TBL_MAX_RANGES = MAXR;
     __shared__ uint32_t cur[TBL_MAX_RANGES], tcount[TBL_MAX_RANGES], toff[TBL_MAX_RANGES], wsum[TBL_MAX_RANGES / 64];
     const uint32_t ranges = tp.ranges, fmask = (1u << tp.fbits) - 1u;
     __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
@@ -702,6 +718,18 @@ __global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__
         __syncthreads();
         if (tid < ranges) cur[tid] += tcount[tid];
     }
+}
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                              const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
+                                                              uint32_t table_n, uint32_t base_off, TblPlan tp, uint32_t *__restrict__ presort,
+                                                              uint16_t *__restrict__ presort_fine) {
+    tmsm_coarse_scatter_body<TBL_MAX_RANGES>(digits, n, nchunks, chunk_len, chist, cstart, table_n, base_off, tp, presort, presort_fine);
+}
+__global__ __launch_bounds__(1024) void k_tmsm_coarse_scatter2(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
+                                                               const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart,
+                                                               uint32_t table_n, uint32_t base_off, TblPlan tp, uint32_t *__restrict__ presort,
+                                                               uint16_t *__restrict__ presort_fine) {
+    tmsm_coarse_scatter_body<2 * TBL_MAX_RANGES>(digits, n, nchunks, chunk_len, chist, cstart, table_n, base_off, tp, presort, presort_fine);
 }
 // Fine sort of run r: counts and absolute starts of its 1024 buckets, entries placed in [lo, hi) of `sorted` -- and the
 // task lists the general pipeline builds with four more kernels (k_scan_blocks/_top, k_msm_task_bins, k_msm_task_order):
@@ -1502,7 +1530,7 @@ struct WorkspaceNeed {
     size_t n, counts, sorted, tasks, hist, windows;
 };
 static void workspace_release(MsmWorkspace &ws) {
-    if (debug_trace()) fprintf(stderr, "[halo] workspace release %p (graph %p)\n", (void *)&ws, (void *)ws.graph_exec);
+    if (debug_trace()) fprintf(stderr, "[halo] workspace release %p\n", (void *)&ws);
     uint64_t *p64[] = {ws.d_canon, ws.d_winsum};
     uint32_t *p32[] = {ws.d_buckets, ws.d_seg, ws.d_counts, ws.d_starts, ws.d_hist, ws.d_blockoff, ws.d_sorted, ws.d_presort, ws.d_ntask, ws.d_toff,
                        ws.d_tblockoff, ws.d_biglist, ws.d_meta, ws.d_task_g, ws.d_order};
@@ -1510,7 +1538,7 @@ static void workspace_release(MsmWorkspace &ws) {
     for (auto p : p32) (void)hipFree(p);
     (void)hipFree(ws.d_fine16);
     if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
-    if (ws.graph_exec) (void)hipGraphExecDestroy(ws.graph_exec);
+    for (auto &g : ws.graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     ws = MsmWorkspace();
 }
 static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need);
@@ -1660,7 +1688,11 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     }
     MsmWorkspace &ws = ctx->wss[slot];
     if (ws.in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
-    ws.plan = MsmPlan{0, 0, 0, members.count, 0, 0};
+    ws.plan = MsmPlan{0, 0, 0, msm_outputs(members), 0, 0};
+    if (members.tagged && (members.count != 1 || mont || !msm_tagged_ready(ctx, d_bases, n))) {
+        set_error("msm: a tagged launch is one canonical scalar array over the context's key with the c = 20 table in place (msm_tagged_ready)");
+        return HALO_E_ARG;
+    }
     if (members.parts < 1 || members.part < 0 || members.part >= members.parts) { set_error("msm: window shard out of range"); return HALO_E_ARG; }
     if (n == 0) { ws.in_flight = true; return HALO_OK; }
     if (members.parts > 1) {  // a shard that owns no window (more shards than windows) contributes the point at infinity
@@ -1682,6 +1714,20 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
             workspace_release(ws);
             int rc = workspace_alloc(ws, need);
             if (rc) return rc;
+        }
+        if (members.tagged) {  // two sets of 2^19 buckets: per-bucket arrays of 2^20, a task per non-empty bucket and per kmax entries beyond
+            const TblPlan tp = ctx->tbl;
+            size_t counts = 2 * (size_t)tp.B, kmax = ctx->task_len > 0 ? (size_t)ctx->task_len : KMAX;
+            size_t tasks = counts + (size_t)tp.W * n / kmax + 1;
+            if (counts > ws.cap_counts || tasks > ws.cap_tasks) {
+                need.n = ws.cap_n; need.sorted = ws.cap_sorted; need.hist = ws.cap_hist; need.windows = ws.cap_windows;
+                need.counts = counts > ws.cap_counts ? counts : ws.cap_counts;
+                need.tasks = tasks > ws.cap_tasks ? tasks : ws.cap_tasks;
+                alloc_epoch_bump(ctx);
+                workspace_release(ws);
+                int rc = workspace_alloc(ws, need);
+                if (rc) return rc;
+            }
         }
     }
     StreamGuard guard(ctx, ctx->streams[slot]);
@@ -1713,27 +1759,40 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     MsmWorkspace::GraphKey key;
     key.bases = d_bases; key.members = members; key.n = n; key.mont = mont ? 1 : 0; key.c = ctx->window_bits; key.span = ctx->reduce_span + 1024 * ctx->task_len + 65536 * (ctx->sort_two_level + 1) + 262144 * (ctx->small_path + 1) + 1048576 * (ctx->table_mode + 1) + 4194304 * (partner + 1);
     bool graphs = ctx->use_graphs && !ctx->prof.on;
-    // A graph is kept while the same key keeps arriving on this slot and this context has not allocated or freed device
-    // memory since it was instantiated (its own workspaces, table, IPA buffers: first use only -- the opens of a loop
-    // allocate nothing, so their graphs survive).  A replay launches exactly the kernels, grids and arguments a fresh
+    // A graph is kept while this context has not allocated or freed device memory since it was instantiated (its own
+    // workspaces, table, IPA buffers: first use only -- the opens of a loop allocate nothing, so their graphs survive), up to
+    // MsmWorkspace::GRAPHS keys per slot.  A replay launches exactly the kernels, grids and arguments a fresh
     // enqueue with this key would.  The GPU memory fault of round 1 ("graph REPLAY ... n=262144") was a kernel with
     // SCRATCH inside a replayed graph (k_msm_reduce1: 256 VGPRs, 12 B/lane of spill) after the queue's scratch had been
     // re-assigned -- not a stale pointer: csrc/check_resources.py now fails the build if any kernel uses scratch.
-    if (ws.graph_exec && (!(key == ws.graph_key) || ws.graph_epoch != ctx->alloc_epoch)) {
-        (void)hipGraphExecDestroy(ws.graph_exec);
-        ws.graph_exec = nullptr;
-        ws.graph_key = MsmWorkspace::GraphKey();
+    if (ws.graph_epoch != ctx->alloc_epoch) {
+        for (auto &g : ws.graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g = MsmWorkspace::CachedGraph();
+        }
+        ws.graph_epoch = ctx->alloc_epoch;
     }
-    if (graphs && ws.graph_exec && key == ws.graph_key) {
+    static const int cache_n = [] {  // development switch: HALO_GRAPH_CACHE=1 is the single graph per slot of rounds 1-3
+        int v = getenv("HALO_GRAPH_CACHE") ? atoi(getenv("HALO_GRAPH_CACHE")) : MsmWorkspace::GRAPHS;
+        return v < 1 ? 1 : (v > MsmWorkspace::GRAPHS ? MsmWorkspace::GRAPHS : v);
+    }();
+    MsmWorkspace::CachedGraph *hit = nullptr;
+    for (int k = 0; k < cache_n; ++k)
+        if (ws.graphs[k].exec && key == ws.graphs[k].key) hit = &ws.graphs[k];
+    if (graphs && hit) {
         if (debug_trace()) fprintf(stderr, "[halo] graph REPLAY ctx=%p slot=%d n=%zu\n", (void *)ctx, slot, n);
-        HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
-        ws.plan = ws.graph_plan;
+        HALO_HIP(hipGraphLaunch(hit->exec, ctx->streams[slot]));
+        hit->used = ++ws.graph_clock;
+        ws.plan = hit->plan;
         ws.in_flight = true;
         if (partner >= 0) { ws.borrowed = partner; ctx->wss[partner].in_flight = true; ctx->wss[partner].lent_from = slot; }
         return HALO_OK;
     }
-    bool capture = graphs && key == ws.seen_key;
-    ws.seen_key = key;
+    bool capture = false;
+    if (graphs) {
+        for (int k = 0; k < cache_n; ++k) capture = capture || key == ws.seen[k];
+        if (!capture) { ws.seen[ws.seen_at] = key; ws.seen_at = (ws.seen_at + 1) % cache_n; }
+    }
     if (debug_trace()) fprintf(stderr, "[halo] msm enqueue ctx=%p slot=%d n=%zu batch=%d part=%d/%d capture=%d\n", (void *)ctx, slot, n, members.count, members.part, members.parts, (int)capture);
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
     int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
@@ -1742,14 +1801,18 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         hipError_t e = hipStreamEndCapture(ctx->streams[slot], &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-        if (ws.graph_exec) { (void)hipGraphExecDestroy(ws.graph_exec); ws.graph_exec = nullptr; }
-        e = hipGraphInstantiate(&ws.graph_exec, graph, nullptr, nullptr, 0);
+        MsmWorkspace::CachedGraph *victim = &ws.graphs[0];
+        for (int k = 0; k < cache_n; ++k)
+            if (!ws.graphs[k].exec) { victim = &ws.graphs[k]; break; }
+            else if (ws.graphs[k].used < victim->used) victim = &ws.graphs[k];
+        if (victim->exec) { (void)hipGraphExecDestroy(victim->exec); *victim = MsmWorkspace::CachedGraph(); }
+        e = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { ws.graph_exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
-        ws.graph_key = key;
-        ws.graph_plan = ws.plan;
-        ws.graph_epoch = ctx->alloc_epoch;
-        HALO_HIP(hipGraphLaunch(ws.graph_exec, ctx->streams[slot]));
+        if (e != hipSuccess) { victim->exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
+        victim->key = key;
+        victim->plan = ws.plan;
+        victim->used = ++ws.graph_clock;
+        HALO_HIP(hipGraphLaunch(victim->exec, ctx->streams[slot]));
     }
     if (rc) return rc;
     ws.in_flight = true;
@@ -1824,6 +1887,15 @@ static int table_build(halo_ctx *ctx) {
     ctx->table_status = 2;
     return HALO_OK;
 }
+// A tagged launch (MsmBatch::tagged) has no table-free form: the caller asks first and keeps its two plain launches otherwise
+// (no table yet -- the first MSM over the key builds it --, table mode off, a forced window size, the small-key plan).
+bool msm_tagged_ready(const halo_ctx *ctx, const uint32_t *d_bases, size_t n) {
+    static const bool off = getenv("HALO_TAGGED") && atoi(getenv("HALO_TAGGED")) == 0;  // development switch: never
+    if (off || !ctx->d_table || ctx->tbl.c != 20) return false;
+    MsmBatch one;
+    one.tagged = true;
+    return table_eligible(ctx, d_bases, one, n);
+}
 // halo_set_table_mode(ctx, 0): the table's memory goes back to the device (its launches have drained: every slot is idle)
 int table_release(halo_ctx *ctx) {
     if (!ctx->d_table) return HALO_OK;
@@ -1856,6 +1928,7 @@ void table_detach(halo_ctx *ctx) {
 static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const MsmBatch &members, size_t n) {
     if (ctx->table_mode == 0 || ctx->window_bits != 0 || members.parts != 1) return false;
     TblPlan tp = table_plan(ctx->n);
+    if (members.tagged && (tp.c != 20 || n > TBL_PIECE || members.count != 1)) return false;  // (one piece, 2 x 512 coarse ranges)
     if (members.count != 1) {  // batches: small-key plan only, members over the same points, count * ranges coarse ranges at most 512
         uint32_t cpow = 1;
         while ((int)cpow < members.count) cpow <<= 1;
@@ -1874,7 +1947,7 @@ static RcShape table_rc_shape(int c, uint32_t B, uint32_t sets) {
     static const bool off = getenv("HALO_REDUCE_RC") && atoi(getenv("HALO_REDUCE_RC")) == 0;  // development switch: the older form
     RcShape r;
     if (off) return r;
-    if (c == 20 && sets == 1 && B == (1u << 19)) { r.lg_rows = 9; r.lg_cols = 10; r.per = 16; }
+    if (c == 20 && (sets == 1 || sets == 2) && B == (1u << 19)) { r.lg_rows = 9; r.lg_cols = 10; r.per = 16; }  // (2 sets: a tagged launch, 2048 waves)
     else if (c == 17 && B == (1u << 16) && (sets == 1 || sets == 2 || sets == 4 || sets == 8)) { r.lg_rows = 8; r.lg_cols = 8; r.per = sets == 1 ? 4 : (int)(2 * sets); }
     return r;
 }
@@ -1890,7 +1963,7 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
     const TblPlan tp = table_launch_plan(ctx, members.count);
     size_t pieces = tp.c == 20 ? (n + TBL_PIECE - 1) / TBL_PIECE : 1;
     uint32_t cpow = 1;  // a batch (small-key plan, one piece) lays its members' bucket sets side by side: a power of two of them
-    while ((int)cpow < members.count) cpow <<= 1;
+    while ((int)cpow < msm_outputs(members)) cpow <<= 1;
     const RcShape rcs = table_rc_shape(tp.c, tp.B, cpow);
     if (2 * tp.vw * pieces * cpow > ws.cap_windows || rc_points(rcs) * cpow * pieces > ws.cap_windows) {
         set_error("msm: table plan exceeds workspace");
@@ -1921,7 +1994,7 @@ static int tmsm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t
         HALO_HIP(hipStreamWaitEvent(mine, ctx->ev_piece[slot][1], 0));
     }
     MsmPlan p;
-    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = members.count; p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
+    p.c = tp.c; p.W = tp.W; p.B = tp.B; p.batch = msm_outputs(members); p.w0 = 0; p.w1 = tp.W; p.table_vw = (int)tp.vw; p.table_vw_bits = tp.vw_bits;
     p.table_pieces = (int)pieces;
     p.table_sets = (int)cpow;
     p.table_rc = rcs.per != 0;
@@ -1935,7 +2008,7 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
                               uint64_t *h_dst) {
     TblPlan tp = table_launch_plan(ctx, members.count);
     uint32_t cpow = 1;
-    while ((int)cpow < members.count) cpow <<= 1;
+    while ((int)cpow < msm_outputs(members)) cpow <<= 1;
     size_t entries = (size_t)tp.W * n * members.count;
     if (n > ws.cap_n || entries > ws.cap_sorted || (size_t)tp.B * cpow > ws.cap_counts) { set_error("msm: table plan exceeds workspace"); return HALO_E_ARG; }
     if (!ws.d_fine16) {
@@ -1947,8 +2020,8 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     uint32_t *d_digits = reinterpret_cast<uint32_t *>(ws.d_canon);  // 4 * W n bytes per member <= 2 * cap_sorted
     TblScalars srcs{};
     for (int b = 0; b < members.count; ++b) srcs.p[b] = members.scalars[b] + 4 * soff;
-    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256), (unsigned)members.count), dim3(256), 0, srcs, mont ? 1 : 0, (uint32_t)n,
-                tp, d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
+    HALO_LAUNCH(ctx, "k_tmsm_recode", k_tmsm_recode, dim3((unsigned)((n + 255) / 256), (unsigned)members.count), dim3(256), 0, srcs, mont ? 1 : 0,
+                members.tagged ? 1 : 0, (uint32_t)n, tp, d_digits, ws.d_meta, ws.d_blockoff, ws.d_tblockoff);
     // from here on: ONE MSM of rows = count * W digit rows over sets * B buckets
     const uint32_t rows = (uint32_t)tp.W * (uint32_t)members.count;
     tp.B *= cpow; tp.ranges *= cpow; tp.vw *= cpow;
@@ -1962,12 +2035,16 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     if (ctx->task_len > 0) kmax = (uint32_t)ctx->task_len;
     else if (entries <= (size_t)16 * 131072) kmax = 16;
     else if (entries <= (size_t)32 * 131072) kmax = 32;
-    HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, tp, chist);
+    const bool wide = tp.ranges > TBL_MAX_RANGES;  // (two bucket sets of the c = 20 plan: 1024 coarse ranges)
+    if (wide) HALO_LAUNCH(ctx, "k_tmsm_coarse_hist2", k_tmsm_coarse_hist2, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, tp, chist);
+    else HALO_LAUNCH(ctx, "k_tmsm_coarse_hist", k_tmsm_coarse_hist, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, tp, chist);
     uint32_t *rtotal = cstart + tp.ranges + 1;
     HALO_LAUNCH(ctx, "k_tmsm_scan_chunks", k_tmsm_scan_chunks, dim3(tp.ranges), b256, 0, chist, rows * nchunks, tp.ranges, rtotal);
     HALO_LAUNCH(ctx, "k_tmsm_scan_ranges", k_tmsm_scan_ranges, dim3(1), dim3(tp.ranges), 0, rtotal, cstart);
-    HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
-                (uint32_t)ctx->n, base_off, tp, ws.d_presort, ws.d_fine16);
+    if (wide) HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter2", k_tmsm_coarse_scatter2, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
+                          (uint32_t)ctx->n, base_off, tp, ws.d_presort, ws.d_fine16);
+    else HALO_LAUNCH(ctx, "k_tmsm_coarse_scatter", k_tmsm_coarse_scatter, gridc, b1024, 0, d_digits, (uint32_t)n, nchunks, chunk_len, chist, cstart,
+                     (uint32_t)ctx->n, base_off, tp, ws.d_presort, ws.d_fine16);
     HALO_LAUNCH(ctx, "k_tmsm_fine_sort", k_tmsm_fine_sort, dim3(tp.ranges), b1024, TBL_STAGE * 4, ws.d_presort, ws.d_fine16, cstart, kmax, tp, ws.d_counts,
                 ws.d_starts, ws.d_ntask, ws.d_toff, ws.d_task_g, ws.d_biglist, ws.d_meta, ws.d_sorted);
     uint32_t total = tp.B;

@@ -555,6 +555,46 @@ def test_open_with_fold_table_matches_oracle(hal, lg):
         c.close()
 
 
+def test_open_2_20_first_rounds_as_one_tagged_launch_equal_two_plain_launches(hal):
+    """Rounds 0 and 1 of an open over the full 2^20-point key: L and R from ONE launch sequence over the fixed-base table (one
+    scalar array, bit 255 of an element = its bucket set: msm.hip MsmBatch::tagged, ipa.hip k_nofold_expand_tagged) against the
+    same open with the table switched off (two plain launches through the table-free pipeline): proofs equal word for word,
+    for a dense, a hiding and a half-empty polynomial (zero scalars carry a tag too); both verify."""
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 20; d = n - 1
+    c = hal._lib.Context(urs_n=n)
+    try:
+        c.set_fold_table(0)  # (not what is tested here; saves its 35 GB and 0.2 s)
+        buf = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
+        c.rng_scalars_dev(0x7A66ED, n + 2, buf.data_ptr())
+        co = np.ascontiguousarray(buf.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
+        coeffs, zw = np.ascontiguousarray(co[:n]), co[n:]
+        sparse = coeffs.copy()
+        sparse[: n // 2] = 0
+        sparse[n // 2 + 5 :: 7] = 0
+        for poly, w in ((coeffs, None), (coeffs, zw[1]), (sparse, None)):
+            c.set_table_mode(-1)
+            C = pcdl.commit(c, poly, d, w)  # (the first MSM over the key builds the table)
+            c.prof_enable(1); c.prof_reset()
+            got = pcdl.open(c, [11], poly, C, d, zw[0], w)
+            ran = c.prof()
+            c.prof_enable(0)
+            assert ran["k_nofold_expand_tagged"][1] == 2 and ran["k_tmsm_coarse_scatter2"][1] == 2, "rounds 0 and 1 did not take the tagged launch"
+            assert "k_nofold_expand" in ran and ran["k_tmsm_recode"][1] == (2 if w is None else 3), "only rounds 0 and 1 (and a hiding open's commitment) run over the table"
+            assert pcdl.open(c, [11], poly, C, d, zw[0], w).tolist() == got.tolist()  # (replayed launch graphs)
+            c.set_table_mode(0)
+            c.prof_enable(1); c.prof_reset()
+            want = pcdl.open(c, [11], poly, C, d, zw[0], w)
+            ran = c.prof()
+            c.prof_enable(0)
+            assert ran.get("k_nofold_expand_tagged", (0, 0))[1] == 0 and ran.get("k_tmsm_recode", (0, 0))[1] == 0
+            assert got.tolist() == want.tolist()
+            pcdl.check_proof(c, C, d, zw[0], c.poly_eval(poly, zw[0]), got)
+    finally:
+        c.close()
+
+
 def test_msm_affine_more_generators_than_the_context_holds(hal, ctx):
     """halo_msm_affine over more generators than the context has points: consecutive chunks, partial sums added on the host"""
     from halo_accumulation_amd import group
