@@ -14,6 +14,7 @@ rank reduces its share to one point and the partials are all-gathered over RCCL 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -45,6 +46,10 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # Python's cyclic collector stays off during the run and is called between the legs instead: with the arrays of the earlier
+    # legs alive a full collection took 4-6 ms and landed in every fifth open + check (16.7 ms -> 21-23 ms: four of 24 samples in
+    # profiles/r04's first bench line); the library's host side is C++, a caller in Rust has no collector at all.
+    gc.disable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -55,7 +60,7 @@ def main():
     ap.add_argument("--shard", choices=["window", "index", "auto"], default="auto",
                     help="N > 1: split every MSM by Pippenger windows (key and scalars replicated) or by base/scalar index; "
                          "auto = index blocks while a rank's block has >= 2^17 points (a fixed-base-table MSM), else windows")
-    ap.add_argument("--open-steps", type=int, default=5, help="PCDL open+check repetitions at N=1 (0 = skip)")
+    ap.add_argument("--open-steps", type=int, default=12, help="PCDL open+check repetitions at N=1 (0 = skip)")
     ap.add_argument("--cpu-msms", type=int, default=2, help="oracle MSMs timed for cpu_baseline at N=1 (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until this much time is covered; the median repetition is reported")
     ap.add_argument("--one-process", action="store_true",
@@ -361,7 +366,8 @@ def main():
         gpu_side = {}  # what the CPU leg compares: inputs and GPU outputs of the small (2^cpu_log_n) open / ASDL runs
 
         def median(xs):
-            return sorted(xs)[len(xs) // 2]
+            xs = sorted(xs)
+            return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
         if args.host_steps > 0:
             # the same MSM with the scalars handed over in HOST memory (halo_msm: 32 MiB H2D per MSM at n = 2^20, pageable):
@@ -464,6 +470,7 @@ def main():
 
             def timed(fn, reps):
                 torch.cuda.synchronize()
+                gc.collect()  # (the cyclic collector is off for the whole run, see main(): collected here, between the timed loops)
                 ts, p_ = [], None
                 for _ in range(reps):
                     t0 = time.perf_counter()
@@ -490,7 +497,7 @@ def main():
             assert pi.tolist() == pi_h.tolist() == pi0.tolist()
             ts_b, _ = timed(one, args.open_steps)  # second set, after the host-path runs
             pooled = sorted(ts_a + ts_b)
-            odt = pooled[len(pooled) // 2]  # ONE median over both sets of samples (not the better of two medians)
+            odt = median(pooled)  # ONE median over both sets of samples (not the better of two medians)
             plain_dt = median(ts_plain)
             # check alone, and the kernels of one open with event brackets around every launch
             cts, _ = timed(lambda: pcdl.check_proof(ctx, C, d, zw[0], v, pi), max(args.open_steps, 3))
@@ -635,6 +642,7 @@ def main():
                                              "2^20 products on this chip (tools/fr29_bench.hip), i.e. 4.1 TB/s-equivalent before any load, store or "
                                              "conversion -- see DESIGN.md 4.4"}
         if args.asdl_steps > 0:
+            gc.collect()
             # BASELINE configs[3], the shape of benches/acc.rs:64-98 on a short chain: K x (random_instance + prover), K x verifier,
             # one decider (tests/test_gpu_pcdl_acc.py runs the full 64-step chain)
             from halo_accumulation_amd import acc as A
@@ -714,6 +722,7 @@ def main():
                 gpu_side["asdl_small"] = {"n": small_n, "steps": ks, "accs": accs_s, "instance_plus_prover_ms_each": t_c * 1e3, "verifier_ms_each": t_v * 1e3,
                                           "decider_ms": t_d * 1e3}
         if args.cpu_msms > 0:
+            gc.collect()
             # ---- the CPU leg: the ONLY place that touches oracle/ (the single-thread restatement of the arkworks path the reference
             # runs: "port"), compiled on this host with -march=native.  It is the checker of everything above and the reported baseline.
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it

@@ -1594,6 +1594,9 @@ int msm_workspace_alloc(halo_ctx *ctx, size_t n, int slot) {
     // sorted entries: n * W; the automatic plan has W <= 32 for n >= 4096 (c >= 8) and W <= 64 below
     need.sorted = n >= 4096 ? n * 32 : n * 64;
     need.counts = max_counts();
+    // (a key of the c = 20 table plan: room for the TWO bucket sets of a tagged launch from the start -- growing the workspace at
+    // the first tagged launch cost the first open of a context a second of hipFree / hipMalloc)
+    if (n >= ((size_t)1 << 20) && need.counts < ((size_t)1 << 20)) need.counts = (size_t)1 << 20;
     {   // tasks: one per non-empty bucket plus entries / kmax (kmax = 16 only below 2^18 points, W <= 32 there)
         size_t small = need.sorted < ((size_t)1 << 23) ? need.sorted : ((size_t)1 << 23);
         size_t extra = need.sorted / KMAX > small / 16 ? need.sorted / KMAX : small / 16;
