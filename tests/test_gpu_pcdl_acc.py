@@ -595,6 +595,36 @@ def test_open_2_20_first_rounds_as_one_tagged_launch_equal_two_plain_launches(ha
         c.close()
 
 
+def test_open_over_the_first_half_of_a_2_21_point_key_equals_the_2_20_point_context(hal):
+    """The generators of a context are a prefix-consistent sequence (main.rs:18-32), so an open of a degree-(2^20 - 1) polynomial
+    over the first half of a 2^21-point key must be the open of a 2^20-point context, word for word -- through the larger
+    context's table (built for 2^21 points, indexed with its own stride) and the tagged launch of rounds 0 and 1 over a prefix."""
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 20; d = n - 1
+    big, small = hal._lib.Context(urs_n=2 * n), hal._lib.Context(urs_n=n)
+    try:
+        for c in (big, small):
+            c.set_fold_table(0)
+        buf = torch.empty((n + 2) * 4, dtype=torch.int64, device="cuda")
+        small.rng_scalars_dev(0x21F0, n + 2, buf.data_ptr())
+        co = np.ascontiguousarray(buf.cpu().numpy().view(np.uint64).reshape(n + 2, 4))
+        coeffs, zw = np.ascontiguousarray(co[:n]), co[n:]
+        for w in (None, zw[1]):
+            Cs, Cb = pcdl.commit(small, coeffs, d, w), pcdl.commit(big, coeffs, d, w)
+            assert Cs.tolist() == Cb.tolist()
+            want = pcdl.open(small, [3], coeffs, Cs, d, zw[0], w)
+            big.prof_enable(1); big.prof_reset()
+            got = pcdl.open(big, [3], coeffs, Cb, d, zw[0], w)
+            ran = big.prof()
+            big.prof_enable(0)
+            assert ran.get("k_nofold_expand_tagged", (0, 0))[1] == 2, "rounds 0 and 1 over the prefix did not take the tagged launch"
+            assert got.tolist() == want.tolist()
+            pcdl.check_proof(big, Cb, d, zw[0], small.poly_eval(coeffs, zw[0]), got)
+    finally:
+        big.close(); small.close()
+
+
 def test_msm_affine_more_generators_than_the_context_holds(hal, ctx):
     """halo_msm_affine over more generators than the context has points: consecutive chunks, partial sums added on the host"""
     from halo_accumulation_amd import group
