@@ -559,7 +559,8 @@ def test_open_2_20_first_rounds_as_one_tagged_launch_equal_two_plain_launches(ha
     """Rounds 0 and 1 of an open over the full 2^20-point key: L and R from ONE launch sequence over the fixed-base table (one
     scalar array, bit 255 of an element = its bucket set: msm.hip MsmBatch::tagged, ipa.hip k_nofold_expand_tagged) against the
     same open with the table switched off (two plain launches through the table-free pipeline): proofs equal word for word,
-    for a dense, a hiding and a half-empty polynomial (zero scalars carry a tag too); both verify."""
+    for a dense, a hiding, a half-empty (zero scalars carry a tag too) and a constant-coefficient polynomial (every point of a
+    set in ONE bucket per window: the oversized-run and many-task paths of the sort with two sets); all verify."""
     import torch
     from halo_accumulation_amd import pcdl
     n = 1 << 20; d = n - 1
@@ -573,7 +574,8 @@ def test_open_2_20_first_rounds_as_one_tagged_launch_equal_two_plain_launches(ha
         sparse = coeffs.copy()
         sparse[: n // 2] = 0
         sparse[n // 2 + 5 :: 7] = 0
-        for poly, w in ((coeffs, None), (coeffs, zw[1]), (sparse, None)):
+        flat = np.ascontiguousarray(np.broadcast_to(coeffs[5], coeffs.shape))  # one value: 2^19 points per bucket and set in round 0
+        for poly, w in ((coeffs, None), (coeffs, zw[1]), (sparse, None), (flat, None)):
             c.set_table_mode(-1)
             C = pcdl.commit(c, poly, d, w)  # (the first MSM over the key builds the table)
             c.prof_enable(1); c.prof_reset()
