@@ -586,11 +586,10 @@ template <uint32_t MAXR>
 HALO_DEV void tmsm_coarse_hist_body(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len, const TblPlan &tp,
                                     uint32_t *__restrict__ chist) {
     __shared__ uint32_t cnt[16 * MAXR];
-    constexpr uint32_t TBL_MAX_RANGES = MAXR;
     uint32_t w = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
-    for (uint32_t k = threadIdx.x; k < 16 * TBL_MAX_RANGES; k += 1024) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < 16 * MAXR; k += 1024) cnt[k] = 0;
     __syncthreads();
-    uint32_t *mine = cnt + TBL_MAX_RANGES * (threadIdx.x >> 6);
+    uint32_t *mine = cnt + MAXR * (threadIdx.x >> 6);
     uint32_t lo = chunk * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
     const uint32_t *dg = digits + (size_t)w * n;
     for (uint32_t i = lo + 4 * threadIdx.x; i < hi; i += 4 * 1024) {  // n and chunk_len are multiples of 4
@@ -603,7 +602,7 @@ HALO_DEV void tmsm_coarse_hist_body(const uint32_t *__restrict__ digits, uint32_
     __syncthreads();
     if (threadIdx.x < tp.ranges) {
         uint32_t t = 0;
-        for (int r = 0; r < 16; r++) t += cnt[TBL_MAX_RANGES * r + threadIdx.x];
+        for (int r = 0; r < 16; r++) t += cnt[MAXR * r + threadIdx.x];
         chist[(size_t)blockIdx.x * tp.ranges + threadIdx.x] = t;
     }
 }
@@ -657,8 +656,7 @@ template <uint32_t MAXR>
 HALO_DEV void tmsm_coarse_scatter_body(const uint32_t *__restrict__ digits, uint32_t n, uint32_t nchunks, uint32_t chunk_len,
                                        const uint32_t *__restrict__ chist, const uint32_t *__restrict__ cstart, uint32_t table_n, uint32_t base_off,
                                        const TblPlan &tp, uint32_t *__restrict__ presort, uint16_t *__restrict__ presort_fine) {
-    constexpr uint32_t TBL_MAX_RANGES = MAXR;
-    __shared__ uint32_t cur[TBL_MAX_RANGES], tcount[TBL_MAX_RANGES], toff[TBL_MAX_RANGES], wsum[TBL_MAX_RANGES / 64];
+    __shared__ uint32_t cur[MAXR], tcount[MAXR], toff[MAXR], wsum[MAXR / 64];
     const uint32_t ranges = tp.ranges, fmask = (1u << tp.fbits) - 1u;
     __shared__ uint32_t t_idx[TBL_TILE], t_dest[TBL_TILE];
     __shared__ uint16_t t_fine[TBL_TILE];
@@ -690,11 +688,11 @@ HALO_DEV void tmsm_coarse_scatter_body(const uint32_t *__restrict__ digits, uint
                 uint32_t o = (uint32_t)__shfl_up((int)x, off, 64);
                 if (lane >= (uint32_t)off) x += o;
             }
-            if (lane == 63 && tid < TBL_MAX_RANGES) wsum[tid >> 6] = x;
+            if (lane == 63 && tid < MAXR) wsum[tid >> 6] = x;
             __syncthreads();
             uint32_t before = 0;
 #pragma unroll
-            for (uint32_t wv = 0; wv < TBL_MAX_RANGES / 64; wv++) before += (wv < (tid >> 6)) ? wsum[wv] : 0u;
+            for (uint32_t wv = 0; wv < MAXR / 64; wv++) before += (wv < (tid >> 6)) ? wsum[wv] : 0u;
             if (tid < ranges) toff[tid] = x + before;
             __syncthreads();
         }
