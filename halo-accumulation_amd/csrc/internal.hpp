@@ -75,6 +75,10 @@ struct MsmPlan {
     int table_sets = 1;      // bucket sets side by side in a batched table launch (members, rounded up to a power of two)
     bool table_rc = false;   // window sums by rows and columns of the bucket index (msm.hip k_msm_reduce_rc): (S, T) pairs per set
     int table_rc_lg_rows = 0, table_rc_lg_cols = 0;
+    // > 0: the launch's last kernel(s) write their sums straight into the slot's pinned buffer and each adds one to the slot's
+    // pinned counter when its last block is through (MsmWorkspace::h_done; one per piece); msm_wait polls the counter.  0: a copy
+    // and a stream wait.
+    int publishers = 0;
 };
 constexpr int MSM_MAX_BATCH = 8;
 // fixed-base table plan of a context (msm.hip: table_plan)
@@ -116,6 +120,8 @@ struct MsmWorkspace {
     uint32_t *d_seg = nullptr;       // W*64 x 2 native XYZZ (S, T per 512-bucket segment)
     uint64_t *d_winsum = nullptr;    // W x 12 (Jacobian)
     uint64_t *h_winsum = nullptr;    // pinned
+    uint32_t *h_done = nullptr;      // pinned: blocks that have published their sums, ever (see MsmPlan::publishers)
+    uint32_t done_expect = 0;        // ... and what it reads once the launches enqueued so far are done
     size_t cap_counts = 0, cap_sorted = 0, cap_tasks = 0, cap_hist = 0, cap_windows = 0;
     MsmPlan plan{};          // plan of the MSM in flight on this slot
     bool in_flight = false;
@@ -270,6 +276,8 @@ struct halo_ctx {
     hipStream_t streams[HALO_SLOTS] = {};
     size_t n = 0;
     uint32_t *d_bases = nullptr;  // n x 32 words (AFF_STRIDE): native affine x | y | -y, one 128-byte line per point (curve.hpp AffN)
+    uint32_t *sink_done = nullptr;             // while a launch is being enqueued: the counter its last kernel publishes to (null: copy + stream wait)
+    int sink_publishers = 0;                   // ... and how many blocks will
     halo::MsmWorkspace wss[HALO_SLOTS];        // slots (workspace + stream) so that independent MSMs can overlap
     halo::Profiler prof;
     std::vector<halo::ProfEntry> prof_merged;  // what halo_prof_count / _get show: this context's entries plus its shards'
@@ -444,9 +452,10 @@ int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, 
 int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
+// (winsum / winsum_plain may be pinned host memory; done: the counter to publish to, or null)
 int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain,
-                       const uint32_t *seg = nullptr);
-int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum);
+                       const uint32_t *seg = nullptr, uint32_t *done = nullptr);
+int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum, uint32_t *done = nullptr, uint32_t *ticket = nullptr);
 int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint32_t base_off, size_t n, const MsmPlan &p, uint32_t Wt,
                  uint32_t kmax);
 int smsm_prepare();

@@ -1536,6 +1536,7 @@ static void workspace_release(MsmWorkspace &ws) {
     for (auto p : p32) (void)hipFree(p);
     (void)hipFree(ws.d_fine16);
     if (ws.h_winsum) (void)hipHostFree(ws.h_winsum);
+    if (ws.h_done) (void)hipHostFree(ws.h_done);
     for (auto &g : ws.graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     ws = MsmWorkspace();
 }
@@ -1577,6 +1578,9 @@ static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) 
     HALO_HIP(hipMalloc(&ws.d_seg, ws.cap_windows * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, ws.cap_windows * 12 * 8));
     HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8));
+    HALO_HIP(hipHostMalloc(&ws.h_done, 64));
+    *ws.h_done = 0;
+    ws.done_expect = 0;
     if (debug_trace())  // address ranges, so that a faulting address can be mapped to a buffer
         fprintf(stderr, "[halo] workspace %p: digits=[%p,+%zu) sorted=[%p,+%zu) presort=[%p,+%zu) partials=[%p,+%zu) hist=[%p,+%zu) counts=%p starts=%p ntask=%p toff=%p task_g=%p order=%p seg=%p winsum=%p\n",
                 (void *)&ws, (void *)ws.d_canon, ws.cap_sorted * 2 + 64, (void *)ws.d_sorted, ws.cap_sorted * 4, (void *)ws.d_presort, ws.cap_sorted * 4,
@@ -1785,6 +1789,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         HALO_HIP(hipGraphLaunch(hit->exec, ctx->streams[slot]));
         hit->used = ++ws.graph_clock;
         ws.plan = hit->plan;
+        ws.done_expect += (uint32_t)ws.plan.publishers;
         ws.in_flight = true;
         if (partner >= 0) { ws.borrowed = partner; ctx->wss[partner].in_flight = true; ctx->wss[partner].lent_from = slot; }
         return HALO_OK;
@@ -1796,7 +1801,14 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     }
     if (debug_trace()) fprintf(stderr, "[halo] msm enqueue ctx=%p slot=%d n=%zu batch=%d part=%d/%d capture=%d\n", (void *)ctx, slot, n, members.count, members.part, members.parts, (int)capture);
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
+    // The launch's last kernel publishes its sums itself (smsm.hip publish(): pinned buffer + pinned counter) unless the event
+    // profiler brackets every launch or HALO_DIRECT_RESULTS=0 asks for the copy + stream wait of rounds 1-3 (development switch).
+    static const bool direct = !(getenv("HALO_DIRECT_RESULTS") && atoi(getenv("HALO_DIRECT_RESULTS")) == 0);
+    ctx->sink_done = direct && !ctx->prof.on ? ws.h_done : nullptr;
+    ctx->sink_publishers = 0;
     int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
+    ctx->sink_done = nullptr;
+    if (!rc) ws.plan.publishers = ctx->sink_publishers;
     if (capture) {
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(ctx->streams[slot], &graph);
@@ -1815,7 +1827,15 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         victim->used = ++ws.graph_clock;
         HALO_HIP(hipGraphLaunch(victim->exec, ctx->streams[slot]));
     }
-    if (rc) return rc;
+    if (rc) {
+        // part of the sequence may be on its way and will publish: the counter is brought back in step before anyone waits on it
+        (void)hipStreamSynchronize(ctx->streams[slot]);
+        if (partner >= 0) (void)hipStreamSynchronize(ctx->streams[partner]);
+        (void)hipGetLastError();
+        ws.done_expect = *(volatile uint32_t *)ws.h_done;
+        return rc;
+    }
+    ws.done_expect += (uint32_t)ws.plan.publishers;
     ws.in_flight = true;
     if (partner >= 0) { ws.borrowed = partner; ctx->wss[partner].in_flight = true; ctx->wss[partner].lent_from = slot; }
     return HALO_OK;
@@ -2066,10 +2086,11 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
         const uint32_t pts = rc_points(rcs) * cpow, nb = (tp.B / cpow) / (64u * (uint32_t)rcs.per);
         uint64_t *d_rc = ws.d_winsum + (size_t)piece * pts * 12;
         HALO_LAUNCH(ctx, "k_msm_reduce_rc", k_msm_reduce_rc, dim3(cpow * 2 * nb), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, rcs, ws.d_seg);
-        int rc = rc_mid_enqueue(ctx, ws.d_seg, pts / 2, d_rc);
+        uint64_t *h_rc = h_dst + (size_t)piece * pts * 12;
+        int rc = rc_mid_enqueue(ctx, ws.d_seg, pts / 2, ctx->sink_done ? h_rc : d_rc, ctx->sink_done, ws.d_meta + 255);
         if (rc) return rc;
         HALO_HIP(hipGetLastError());
-        HALO_HIP(hipMemcpyAsync(h_dst + (size_t)piece * pts * 12, d_rc, (size_t)pts * 96, hipMemcpyDeviceToHost, s));
+        if (!ctx->sink_done) HALO_HIP(hipMemcpyAsync(h_rc, d_rc, (size_t)pts * 96, hipMemcpyDeviceToHost, s));
         return HALO_OK;
     }
     uint64_t *d_out = ws.d_winsum + (size_t)piece * 2 * tp.vw * 12;
@@ -2081,11 +2102,12 @@ static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3(tp.vw * nseg), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff, ws.d_tblockoff, vwB, L, logL,
                 nseg, ws.d_seg);
     {
-        int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, d_out, d_out + 12 * tp.vw);
+        uint64_t *out = ctx->sink_done ? h_dst + (size_t)piece * 2 * tp.vw * 12 : d_out;
+        int rc = quad_final_enqueue(ctx, ws, tp.vw, nseg, logL + 6, out, out + 12 * tp.vw, nullptr, ctx->sink_done);
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(h_dst + (size_t)piece * 2 * tp.vw * 12, d_out, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
+    if (!ctx->sink_done) HALO_HIP(hipMemcpyAsync(h_dst + (size_t)piece * 2 * tp.vw * 12, d_out, (size_t)2 * tp.vw * 96, hipMemcpyDeviceToHost, s));
     return HALO_OK;
 }
 
@@ -2127,7 +2149,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
         int rc = smsm_enqueue(ctx, ws, d_bases, members.base_off[0], n, p, Wt, kmax);
         if (rc) return rc;
         HALO_HIP(hipGetLastError());
-        HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
+        if (!ctx->sink_done) HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
         ws.plan = p;
         return HALO_OK;
     }
@@ -2209,11 +2231,11 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     HALO_LAUNCH(ctx, "k_msm_reduce1", k_msm_reduce1, dim3((unsigned)(Wt * nseg)), dim3(64), 0, ws.d_buckets, ws.d_ntask, ws.d_toff,
                 ws.d_tblockoff, p.B, L, logL, nseg, ws.d_seg);
     {
-        int rc = quad_final_enqueue(ctx, ws, (uint32_t)Wt, nseg, logL + 6, ws.d_winsum, nullptr);
+        int rc = quad_final_enqueue(ctx, ws, (uint32_t)Wt, nseg, logL + 6, ctx->sink_done ? ws.h_winsum : ws.d_winsum, nullptr, nullptr, ctx->sink_done);
         if (rc) return rc;
     }
     HALO_HIP(hipGetLastError());
-    HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
+    if (!ctx->sink_done) HALO_HIP(hipMemcpyAsync(ws.h_winsum, ws.d_winsum, (size_t)Wt * 96, hipMemcpyDeviceToHost, s));
     ws.plan = p;
     return HALO_OK;
 }
@@ -2231,7 +2253,29 @@ int msm_wait(halo_ctx *ctx, int slot, int count) {
         ws.borrowed = -1;
     }
     if (ws.plan.W == 0) return HALO_OK;  // n == 0, or a window shard without windows
-    HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
+    if (ws.plan.publishers > 0) {
+        // the last kernel's blocks count themselves in as they hand over their sums (smsm.hip publish()): poll the pinned counter
+        // instead of waiting for the stream -- and look at the stream now and then, in case a launch has died
+        volatile uint32_t *f = ws.h_done;
+        for (uint32_t spins = 1;; ++spins) {
+            if ((int32_t)(*f - ws.done_expect) >= 0) break;
+            if ((spins & 0x3fffu) == 0) {
+                hipError_t e = hipStreamQuery(ctx->streams[slot]);
+                if (e == hipSuccess) {
+                    if ((int32_t)(*f - ws.done_expect) >= 0) break;
+                    ws.done_expect = *f;
+                    set_error("msm: the launch sequence ended without publishing its results");
+                    return HALO_E_DEVICE;
+                }
+                if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (ctx->prof.on) HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
+    } else {
+        HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));
+    }
     bool others = false;
     for (int k = 0; k < HALO_SLOTS; ++k) others = others || ctx->wss[k].in_flight;
     if (ctx->prof.on && !others) ctx->prof.collect();

@@ -319,6 +319,20 @@ HALO_DEV XyzzN park_get(const uint32_t *park, int Q) {
     return xyzz_load(park + XYZZ_WORDS * Q);
 }
 
+// The last kernel of a launch sequence hands its results to the host itself: the sums are written straight into pinned host
+// memory; the writing blocks count themselves in on a device word (zeroed by the launch's recode kernel) and the last of
+// `total` adds one to a pinned counter (release, system scope) that msm_wait polls -- no copy kernel behind the last kernel
+// and no stream wait on the host.  (One system-scope atomic per launch: one per BLOCK, 52-104 of them on one host word that
+// the host is polling, cost 30 us per round.)
+HALO_DEV void publish(uint32_t *done, uint32_t *ticket, uint32_t total) {
+    if (!done) return;
+    __threadfence_system();  // this block's sums are in host memory before it counts itself in
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == total) {
+        __threadfence_system();
+        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Quad Q holds S (sum of its unit; in registers) and T (its unit's weighted sum, weights 1.. relative to the unit's
 // first bucket; parked in parkT); a unit spans 2^k buckets.  Afterwards quad 0 holds S = sum_Q S_Q (returned in S) and
 // T = sum_Q (T_Q + Q 2^k S_Q) (returned in T).  `live` = number of quads that hold anything, rounded up to a power of two.
@@ -352,7 +366,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void k_smsm_reduce(uint32_t *__restrict__ partial, const uint32_t *__restrict__ bk_first,
                                                         const uint32_t *__restrict__ bk_nt, uint32_t B, uint32_t L, int logL, uint32_t nseg,
                                                         int live_seg, uint32_t *__restrict__ seg, uint32_t *__restrict__ done,
-                                                        uint64_t *__restrict__ winsum) {
+                                                        uint64_t *__restrict__ winsum, uint32_t *__restrict__ published) {
     __shared__ uint32_t xch[64 * XYZZ_WORDS], parkS[64 * XYZZ_WORDS], parkT[64 * XYZZ_WORDS];
     __shared__ uint32_t heavy[64], heavy_n, ticket;
     uint32_t w = blockIdx.x / nseg, s = blockIdx.x % nseg;
@@ -452,12 +466,15 @@ __global__ __launch_bounds__(256, 2) void k_smsm_reduce(uint32_t *__restrict__ p
         block_weighted_sum(S, T, logL + 6, xch, parkS, parkT, Q, ql, live_seg);
         tot = T;
     }
-    if (tid == 0) xyzz_store_jac_words(winsum + 12 * (size_t)w, tot);
+    if (tid == 0) {
+        xyzz_store_jac_words(winsum + 12 * (size_t)w, tot);
+        publish(published, done + 191, gridDim.x / nseg);  // (done = d_meta + 64: word 255 of the launch's small state)
+    }
 }
 
 // one block per window: the segments' (S, T) -> the window sum
 __global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restrict__ seg, uint32_t nseg, int k, int live_seg, uint64_t *__restrict__ winsum,
-                                                       uint64_t *__restrict__ winsum_plain) {
+                                                       uint64_t *__restrict__ winsum_plain, uint32_t *__restrict__ published, uint32_t *__restrict__ ticket) {
     __shared__ uint32_t xch[64 * XYZZ_WORDS], parkS[64 * XYZZ_WORDS], parkT[64 * XYZZ_WORDS];
     uint32_t w = blockIdx.x;
     int tid = threadIdx.x, ql = tid & 3, Q = tid >> 2;
@@ -472,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_smsm_final(const uint32_t *__restric
     if (tid == 0) {
         xyzz_store_jac_words(winsum + 12 * (size_t)w, T);
         if (winsum_plain) xyzz_store_jac_words(winsum_plain + 12 * (size_t)w, S);  // the unweighted sum (table pipeline)
+        publish(published, ticket, gridDim.x);
     }
 }
 
@@ -534,14 +552,17 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     while ((1u << logL) < L) logL++;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
     static const bool fused = getenv("HALO_SMSM_FUSED") && atoi(getenv("HALO_SMSM_FUSED")) != 0;
+    // (one thread per window writes its sum: straight to the slot's pinned buffer when the launch publishes, see publish())
+    uint64_t *out = ctx->sink_done ? ws.h_winsum : ws.d_winsum;
     if (fused || nseg == 1) {
         HALO_LAUNCH(ctx, "k_smsm_reduce", k_smsm_reduce<true>, dim3(Wt * nseg), dim3(256), 0, ws.d_buckets, ws.d_starts, ws.d_counts, p.B, L, logL, nseg,
-                    live_seg, ws.d_seg, ws.d_meta + 64, ws.d_winsum);
+                    live_seg, ws.d_seg, ws.d_meta + 64, out, ctx->sink_done);
     } else {
         HALO_LAUNCH(ctx, "k_smsm_reduce", k_smsm_reduce<false>, dim3(Wt * nseg), dim3(256), 0, ws.d_buckets, ws.d_starts, ws.d_counts, p.B, L, logL, nseg,
-                    live_seg, ws.d_seg, ws.d_meta + 64, ws.d_winsum);
-        HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, logL + 6, live_seg, ws.d_winsum, (uint64_t *)nullptr);
+                    live_seg, ws.d_seg, ws.d_meta + 64, out, (uint32_t *)nullptr);
+        HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, ws.d_seg, nseg, logL + 6, live_seg, out, (uint64_t *)nullptr, ctx->sink_done, ws.d_meta + 255);
     }
+    if (ctx->sink_done) ctx->sink_publishers += 1;
     return HALO_OK;
 }
 
@@ -549,10 +570,11 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
 // per window, 2^k buckets each) -> window sums.  A chain of ~20 dependent point operations run by Wt blocks: the quad
 // form takes 80 us where one wave per window took 130.
 int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t nseg, int k, uint64_t *winsum, uint64_t *winsum_plain,
-                       const uint32_t *seg) {
+                       const uint32_t *seg, uint32_t *done) {
     int live_seg = 1;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
-    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, seg ? seg : ws.d_seg, nseg, k, live_seg, winsum, winsum_plain);
+    HALO_LAUNCH(ctx, "k_smsm_final", k_smsm_final, dim3(Wt), dim3(256), 0, seg ? seg : ws.d_seg, nseg, k, live_seg, winsum, winsum_plain, done, ws.d_meta + 255);
+    if (done) ctx->sink_publishers += 1;
     return HALO_OK;
 }
 
@@ -560,7 +582,7 @@ int quad_final_enqueue(halo_ctx *ctx, MsmWorkspace &ws, uint32_t Wt, uint32_t ns
 // (single points) and leaves (S, T) = (sum E_Q, sum (Q + 1) E_Q) as Jacobian words at winsum[2 w], winsum[2 w + 1]: the same
 // quad-parallel weighted sum as k_smsm_final, fed with S = T = E.  The 24 pairs are combined on the host (msm_combine_member:
 // ~70 additions; a second launch for them was 66 us of latency chain).
-__global__ __launch_bounds__(256, 2) void k_rc_mid(const uint32_t *__restrict__ ent, uint64_t *__restrict__ winsum) {
+__global__ __launch_bounds__(256, 2) void k_rc_mid(const uint32_t *__restrict__ ent, uint64_t *__restrict__ winsum, uint32_t *__restrict__ published, uint32_t *__restrict__ ticket) {
     __shared__ uint32_t xch[64 * XYZZ_WORDS], parkS[64 * XYZZ_WORDS], parkT[64 * XYZZ_WORDS];
     uint32_t w = blockIdx.x;
     int tid = threadIdx.x, ql = tid & 3, Q = tid >> 2;
@@ -571,10 +593,12 @@ __global__ __launch_bounds__(256, 2) void k_rc_mid(const uint32_t *__restrict__ 
     if (tid == 0) {
         xyzz_store_jac_words(winsum + 24 * (size_t)w, S);
         xyzz_store_jac_words(winsum + 24 * (size_t)w + 12, T);
+        publish(published, ticket, gridDim.x);
     }
 }
-int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum) {
-    HALO_LAUNCH(ctx, "k_rc_mid", k_rc_mid, dim3(blocks), dim3(256), 0, entries, winsum);
+int rc_mid_enqueue(halo_ctx *ctx, const uint32_t *entries, uint32_t blocks, uint64_t *winsum, uint32_t *done, uint32_t *ticket) {
+    HALO_LAUNCH(ctx, "k_rc_mid", k_rc_mid, dim3(blocks), dim3(256), 0, entries, winsum, done, ticket);
+    if (done) ctx->sink_publishers += 1;
     return HALO_OK;
 }
 
