@@ -6,6 +6,7 @@
 //
 // This is product code (linked into libhalo_hip.so); it shares nothing with oracle/.
 #pragma once
+#include <x86intrin.h>
 #include <array>
 #include <cstdint>
 #include <cstdlib>
@@ -192,16 +193,34 @@ struct Fp {
         }
         return carry;
     }
+    // Branch-free (the window combine of an MSM is ~250 point doublings in a row on the host, between two rounds of an open, and
+    // half of a doubling's time went into the compare-and-branch form of these two): a + b < 2M < 2^256 never carries out, and
+    // whether M has to come off again is the borrow of the trial subtraction.
     Fp operator+(const Fp &o) const {
-        Fp r;
-        add_limbs(r.l, l, o.l);  // < 2M < 2^256
-        if (geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
-        return r;
+        unsigned long long s0, s1, s2, s3, d0, d1, d2, d3;
+        unsigned char c = _addcarry_u64(0, l[0], o.l[0], &s0);
+        c = _addcarry_u64(c, l[1], o.l[1], &s1);
+        c = _addcarry_u64(c, l[2], o.l[2], &s2);
+        (void)_addcarry_u64(c, l[3], o.l[3], &s3);
+        unsigned char b = _subborrow_u64(0, s0, P::M[0], &d0);
+        b = _subborrow_u64(b, s1, P::M[1], &d1);
+        b = _subborrow_u64(b, s2, P::M[2], &d2);
+        b = _subborrow_u64(b, s3, P::M[3], &d3);
+        const u64 keep = (u64)0 - (u64)b;  // all ones: the sum was below M
+        return Fp{{(s0 & keep) | (d0 & ~keep), (s1 & keep) | (d1 & ~keep), (s2 & keep) | (d2 & ~keep), (s3 & keep) | (d3 & ~keep)}};
     }
     Fp operator-(const Fp &o) const {
-        Fp r;
-        if (sub_limbs(r.l, l, o.l)) add_limbs(r.l, r.l, P::M);
-        return r;
+        unsigned long long d0, d1, d2, d3, r0, r1, r2, r3;
+        unsigned char b = _subborrow_u64(0, l[0], o.l[0], &d0);
+        b = _subborrow_u64(b, l[1], o.l[1], &d1);
+        b = _subborrow_u64(b, l[2], o.l[2], &d2);
+        b = _subborrow_u64(b, l[3], o.l[3], &d3);
+        const u64 back = (u64)0 - (u64)b;  // all ones: the difference went below zero, M goes back on
+        unsigned char c = _addcarry_u64(0, d0, P::M[0] & back, &r0);
+        c = _addcarry_u64(c, d1, P::M[1] & back, &r1);
+        c = _addcarry_u64(c, d2, P::M[2] & back, &r2);
+        (void)_addcarry_u64(c, d3, P::M[3] & back, &r3);
+        return Fp{{r0, r1, r2, r3}};
     }
     Fp operator-() const {
         if (is_zero()) return *this;
@@ -238,9 +257,14 @@ struct Fp {
             t3 = (u64)c;
             t4 = (u64)(c >> 64) + t5;
         }
-        Fp r{{t0, t1, t2, t3}};
-        if (t4 || geq(r.l, P::M)) sub_limbs(r.l, r.l, P::M);
-        return r;
+        // t < 2M: M comes off once if t >= M -- t4 set, or no borrow from the trial subtraction (branch-free, like operator+)
+        unsigned long long d0, d1, d2, d3;
+        unsigned char b = _subborrow_u64(0, t0, P::M[0], &d0);
+        b = _subborrow_u64(b, t1, P::M[1], &d1);
+        b = _subborrow_u64(b, t2, P::M[2], &d2);
+        b = _subborrow_u64(b, t3, P::M[3], &d3);
+        const u64 keep = ((u64)0 - (u64)b) & ((u64)0 - (u64)(t4 == 0));  // all ones: t was below M
+        return Fp{{(t0 & keep) | (d0 & ~keep), (t1 & keep) | (d1 & ~keep), (t2 & keep) | (d2 & ~keep), (t3 & keep) | (d3 & ~keep)}};
     }
     Fp sqr() const { return *this * *this; }
     Fp dbl() const { return *this + *this; }
