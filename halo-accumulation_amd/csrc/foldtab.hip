@@ -15,7 +15,10 @@
 // entry) -- seventy opens' worth of savings.  Mode -1 (default; halo_set_fold_table: 1 = allocated and built at the first
 // full-size open, 0 = never): the first full-size open of a context of 2^18 .. 2^21 points asks for the memory on a helper
 // thread (hipMalloc of 40 GB takes 0.5 ms .. 2 s) and takes the generic kernel; the first later open that finds the memory
-// there builds the table -- a prover chain (acc.rs:190-228: two opens per step) gets it at once, a single open never waits.
+// there builds the table -- a prover chain (acc.rs:190-228: two opens per step) gets it at once, a single open does not wait for
+// the table.  (It may wait for the driver: on a box whose memory this process has not had before, the 40 GB take ~1 s inside
+// hipMalloc and the HIP calls of every other thread of the process queue up behind it -- measured: the first open of a fresh
+// box 1.0 s instead of 39 ms, once; tools/time_acc.py names its slowest steps.  In line it would be the same second.)
 // The memory is OPTIONAL memory: it is reserved against the device's budget (halo_set_memory_budget, default 1/6 of the
 // device) before it is requested, and never more than half of what is free is taken.  No budget, no memory, no table: the
 // generic kernel gives the same points, and the table is tried again later.

@@ -12,11 +12,13 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 n = 1 << lg; d = n - 1
 ctx = h._lib.Context(urs_n=n)
+if os.environ.get("FOLD_TABLE"): ctx.set_fold_table(int(os.environ["FOLD_TABLE"]))  # -1 default, 0 never, 1 at the first open
 rng = [0x48414C4F00000004]
 accs, qss, acc = [], [], None
 t0 = time.perf_counter(); t_inst = 0.0; t_prov = 0.0
+inst_ms = []
 for _ in range(K):
-    t = time.perf_counter(); q = A.random_instance(ctx, rng, d); t_inst += time.perf_counter() - t
+    t = time.perf_counter(); q = A.random_instance(ctx, rng, d); t_inst += time.perf_counter() - t; inst_ms.append((time.perf_counter() - t) * 1e3)
     qs = [q] if acc is None else [A.instance_from_accumulator(ctx, acc, d), q]
     t = time.perf_counter(); acc = A.prover(ctx, rng, d, qs); t_prov += time.perf_counter() - t
     accs.append(acc); qss.append(qs)
@@ -37,4 +39,6 @@ print(json.dumps({"config": "ASDL over %d accumulated instances, n=2^%d, 1 GPU" 
                   "slow_check_s (K deciders, benches/acc.rs:100-106, extrapolated from %d)" % min(K, 8): t_slow * K,
                   "fold_table_build_ms (inside the chain: the second full-size open of the context builds the comb table, once)": ctx.info(2) / 1e3,
                   "prover_chain_s_without_the_table_build": t_chain - ctx.info(2) / 1e6,
+                  "slowest_random_instances (step, ms)": sorted([(round(m, 1), i) for i, m in enumerate(inst_ms)], reverse=True)[:3],
+                  "random_instance_ms_median": sorted(inst_ms)[len(inst_ms) // 2],
                   "all_accepted": True}))
