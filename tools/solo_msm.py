@@ -14,6 +14,6 @@ for _ in range(4): r = ctx.msm_dev(d.data_ptr(), n)
 ts = []
 for _ in range(K):
     t0 = time.perf_counter(); r2 = ctx.msm_dev(d.data_ptr(), n); ts.append(time.perf_counter() - t0)
-assert r2.tolist() == r.tolist()
+    assert r2.tolist() == r.tolist()  # (every repetition: the pieces of a large MSM publish their sums to one counter)
 print("lg=%d solo %.3f ms (min %.3f)  result %016x" % (lg, sorted(ts)[len(ts) // 2] * 1e3, min(ts) * 1e3, int(r[0])))
 ctx.close()
