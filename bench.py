@@ -726,7 +726,7 @@ def main():
             # ---- the CPU leg: the ONLY place that touches oracle/ (the single-thread restatement of the arkworks path the reference
             # runs: "port"), compiled on this host with -march=native.  It is the checker of everything above and the reported baseline.
             import orc  # the oracle: only this cpu_baseline / bit-exactness leg uses it
-            build_timings = orc.select_fastest()  # portable and -march=native builds timed on this host, the faster one kept
+            build_timings = orc.select_fastest()  # clang / gcc x portable / -march=native builds timed on this host, the fastest one kept
             gs = ctx.read_bases()
             sc_all = sc_host
             assert sc_all.tolist()[:4] == orc.rng_scalars(0x48414C4F00000002, 4)[0].tolist()  # same stream as the tests
@@ -757,13 +757,16 @@ def main():
                 th.join()
             par_dt = time.perf_counter() - t0
             assert all(b.tolist() == want.tolist() for b in box)
-            build = "oracle/halo_cpu.c, gcc %s (the faster of the builds timed on this host: %s)" % (
+            build = "oracle/halo_cpu.c, %s (the fastest of the builds timed on this host: %s)" % (
                 orc.BUILD_FLAGS, ", ".join("%s %.1f ms per 2^13-point MSM" % (k, v * 1e3) for k, v in sorted(build_timings.items())))
+            ns_product = orc.ns_per_field_product()
             result["cpu_baseline_all_cores"] = {"value": T / par_dt, "unit": "MSM/s", "cores": T, "kind": "port", "cpu_model": cpu_model,
                                                 "sample": "%d concurrent MSMs at n=2^%d, one oracle thread each" % (T, args.log_n)}
             result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "MSM/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "build": build,
                                       "sample": "%d full MSM(s) at n=2^%d, oracle/halo_cpu.c msm_bigint_wnaf (c=%d), 1 thread" % (args.cpu_msms, args.log_n, (args.log_n * 69) // 100 + 2),
-                                      "host_cpus": os.cpu_count()}
+                                      "host_cpus": os.cpu_count(), "ns_per_field_product": ns_product,
+                                      "ns_per_field_product_note": "Fq Montgomery product (4 x 64-bit limbs, ark-ff 0.5 no-carry CIOS restated), throughput over four "
+                                                                   "independent chains, measured in this run on this host with the build named above"}
             if "open_small" in gpu_side:
                 # pcdl::open + check (pcdl.rs:120-242,323-342) on one core at the reference's own size, the same polynomial the GPU just
                 # opened: proofs compared bit for bit; then pcdl::check at the FULL size on the GPU's full-size proof (one MSM of n

@@ -10,6 +10,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libhalo_hip.so")
+DEV_LIB_PATH = os.path.join(PKG, "libhalo_hip_dev.so")
 
 HALO_OK, HALO_E_ASSERT, HALO_E_REJECT, HALO_E_ARG, HALO_E_DEVICE = 0, -1, -2, -3, -4
 
@@ -95,7 +96,6 @@ _SIGS = {
     "halo_pcdl_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, u64p, u64p]),
     "halo_pcdl_succinct_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p]),
     "halo_pcdl_succinct_check_batch": (C.c_int, [C.c_void_p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
-    "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_pcdl_check": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p]),
     "halo_pcdl_check_partial": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u64p, u64p]),
     "halo_pcdl_open_sharded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), u64p, C.c_size_t, C.c_size_t, u64p, C.c_size_t,
@@ -118,23 +118,30 @@ _SIGS = {
     "halo_prof_reset": (C.c_int, [C.c_void_p]),
     "halo_prof_count": (C.c_int, [C.c_void_p]),
     "halo_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
-    "halo_bench_fr_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int]),
-    "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_msm_dev_begin_part": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "halo_msm_dev_batch_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "halo_msm_dev_batch_end": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, u64p]),
-    "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
-    "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
-    "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
-    "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_table_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_fold_table": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_ctx_info": (C.c_size_t, [C.c_void_p, C.c_int]),
     "halo_set_memory_budget": (C.c_int, [C.c_void_p, C.c_size_t]),
-    "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
-    "halo_set_fold_async": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_point_sum": (C.c_int, [u64p, C.c_size_t, u64p]),
     "halo_rng_scalars_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_void_p]),
+}
+
+# libhalo_hip_dev.so (include/halo_accumulation_dev.h): experiment knobs, primitive test hooks, fault injectors.  Loaded only
+# when one of these is called -- tests and tools/; the product path (pcdl.py, acc.py, sharded.py, bench.py's timed legs) never does.
+_DEV_SIGS = {
+    "halo_dev_hook": (C.c_int, [C.c_char_p, C.c_long]),
+    "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_bench_fr_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int]),
+    "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_reduce_span": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_task_len": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_sort_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_small_path": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_fold_levels": (C.c_int, [C.c_void_p, C.c_int]),
+    "halo_set_fold_async": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_set_ipa_switch": (C.c_int, [C.c_void_p, C.c_size_t]),
     "halo_set_graphs": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_test_glv_digits": (C.c_int, [u64p, C.POINTER(C.c_uint8), C.POINTER(C.c_int)]),
@@ -146,6 +153,10 @@ _SIGS = {
 
 def declared_symbols():
     return sorted(_SIGS)
+
+
+def declared_dev_symbols():
+    return sorted(_DEV_SIGS)
 
 
 def load():
@@ -161,13 +172,43 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)  # (global: the development library resolves its internals against THIS copy)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
+        _lib = _Lib(lib)
     return _lib
+
+
+class _Lib:
+    """The product library; names of the development interface resolve to libhalo_hip_dev.so, loaded at their first use."""
+
+    def __init__(self, product):
+        self._product = product
+        self._dev = None
+
+    def dev(self):
+        if self._dev is None:
+            if not os.path.exists(DEV_LIB_PATH):
+                raise HaloError("libhalo_hip_dev.so is missing: run __graft_entry__.build()")
+            dev = C.CDLL(DEV_LIB_PATH)
+            for name, (res, args) in _DEV_SIGS.items():
+                fn = getattr(dev, name)
+                fn.restype = res
+                fn.argtypes = args
+            self._dev = dev
+        return self._dev
+
+    def __getattr__(self, name):
+        if name in _DEV_SIGS:
+            return getattr(self.dev(), name)
+        return getattr(self._product, name)
+
+
+def dev_hook(name: str, value: int) -> None:
+    """fault injectors / forced test paths of the development library (csrc/tuning.hpp DevHooks); "reset" switches all off"""
+    check(load().halo_dev_hook(name.encode(), int(value)))
 
 
 def ptr(a):

@@ -78,20 +78,15 @@ static int ctx_alloc_common(halo_ctx *ctx, int device, size_t n) {
     HALO_HIP(hipMalloc(&ctx->d_tmp_c, 16384 * 8));
     HALO_HIP(hipHostMalloc(&ctx->h_pinned, 4096));
     HALO_HIP(hipHostMalloc(&ctx->h_wintab, 8192));
-    if (const char *e = getenv("HALO_GRAPHS")) ctx->use_graphs = atoi(e) != 0;  // HALO_GRAPHS=0: never replay launch graphs
-    if (const char *e = getenv("HALO_FOLD_ASYNC")) ctx->fold_async = atoi(e);  // -1 automatic, 0 every fold in line, 1 beside the rounds wherever possible (halo_set_fold_async)
+    if (tuning().graphs >= 0) ctx->use_graphs = tuning().graphs != 0;  // HALO_GRAPHS=0: never replay launch graphs
+    if (tuning().fold_async > -2) ctx->fold_async = tuning().fold_async;  // -1 automatic, 0 every fold in line, 1 beside the rounds wherever possible (halo_set_fold_async)
+    host::g_inv_fermat = tuning().host_inv_fermat;
     return msm_workspace_alloc(ctx, n, 0);
 }
 
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // guard used by every entry point
-#define HALO_CTX(ctx)                                                 \
-    do {                                                              \
-        if (!(ctx)) { halo::set_error("null context"); return HALO_E_ARG; } \
-        hipError_t _e = hipSetDevice((ctx)->device);                  \
-        if (_e != hipSuccess) return halo::hip_fail(_e, "hipSetDevice"); \
-    } while (0)
 
 int upload_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words) {
     if (words == 0) return HALO_OK;
@@ -464,8 +459,64 @@ int halo_msm_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t
 }
 int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out[12]) { return halo_msm_dev_end(ctx, slot, out); }
 
+} // extern "C"
+// halo_msm, the call the reference's shim makes (integration/ffi.rs point_dot_affine: a Vec of scalars in pageable memory, one
+// synchronous call).  One copy in front of one launch sequence leaves the GPU idle for the whole copy (32 MiB at PCIe speed:
+// 0.65 of 1.95 ms at n = 2^20).  An MSM is a sum over index stretches, so a large one over the key's c = 20 table runs as P
+// stretches on P slots: stretch k's scalars are copied on slot k's stream directly in front of its launch sequence, the copies
+// queue up behind one another on the copy engine and every stretch's kernels start as soon as ITS scalars are there -- under
+// the copies of the stretches behind it.  The stretches' points are added on the host in index order.  Same result, bit for
+// bit (points written by the library are normalised).  Not taken: multi-device contexts (each shard copies its own block over
+// its own link already), contexts without the c = 20 table (the first MSM of a context builds it), any slot busy.
+static int host_pieces_wanted(const halo_ctx *ctx, size_t n) {
+    const int P = halo::tuning().host_pieces;
+    if (P < 2 || !ctx->shards.empty() || !ctx->d_table || ctx->tbl.c != 20 || ctx->table_mode == 0 || ctx->window_bits != 0) return 1;
+    if (n < ((size_t)1 << 19) || n % (4 * (size_t)P) != 0) return 1;
+    for (int k = 0; k < P; ++k)
+        if (ctx->wss[k].in_flight || ctx->wss[k].lent_from >= 0) return 1;
+    return P;
+}
+static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uint64_t *scalars, int mont, host::Point *out) {
+    const size_t len = n / (size_t)P;
+    int rc = HALO_OK, started = 0;
+    for (int k = 0; k < P && !rc; ++k) {
+        if (!ctx->d_slot_scalars[k]) {
+            alloc_epoch_bump(ctx);
+            hipError_t e = hipMalloc(&ctx->d_slot_scalars[k], (ctx->n < 64 ? 64 : ctx->n) * 32);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
+        }
+        hipError_t e = hipMemcpyAsync(ctx->d_slot_scalars[k], scalars + 4 * len * (size_t)k, len * 32, hipMemcpyHostToDevice, ctx->streams[k]);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync"); break; }
+        MsmBatch one;
+        one.count = 1;
+        one.scalars[0] = ctx->d_slot_scalars[k];
+        one.sub = true;
+        rc = msm_enqueue_batch(ctx, k, ctx->d_bases + 32 * (off + len * (size_t)k), one, mont != 0, len);
+        if (!rc) started = k + 1;
+    }
+    host::Point acc = host::Point::infinity();
+    for (int k = 0; k < started; ++k) {  // (every stretch that went out is collected, whatever happened to the others)
+        host::Point r;
+        int rk = msm_finish(ctx, k, &r);
+        if (rk && !rc) rc = rk;
+        acc = acc + r;
+    }
+    *out = acc;
+    return rc;
+}
+extern "C" {
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int mont, uint64_t out[12]) {
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
+    HALO_CTX(ctx);
+    if (off + n > ctx->n || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    const int P = host_pieces_wanted(ctx, n);
+    if (P > 1) {
+        host::Point r;
+        int rc = msm_host_pieces(ctx, P, off, n, scalars, mont, &r);
+        if (rc) return rc;
+        r.store_normalized(out);
+        return HALO_OK;
+    }
     int rc = halo_msm_begin(ctx, 0, off, n, scalars, mont);
     if (rc) return rc;
     return halo_msm_dev_end(ctx, 0, out);
@@ -725,7 +776,7 @@ extern "C" {
 namespace {
 struct RoundTiming { double enqueue = 0, dots = 0, hterm = 0, wait = 0, combine = 0, fold = 0; long rounds = 0; };
 thread_local RoundTiming g_rt;
-const bool g_rt_on = getenv("HALO_IPA_TIMING") != nullptr;
+const bool g_rt_on = tuning().ipa_timing;
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 // <c_r, G_l>, <c_l, G_r> and the two dot products of one round, without the H' terms
@@ -754,7 +805,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
     // drain, and the H' terms, which need only the dot products, were computed after the MSMs instead of under them.  In
     // the late rounds (an MSM of a few 10^4 additions: the GPU is mostly idle) the MSM's launches go first instead: the
     // three API calls of the dot products would only delay its start.
-    static const int dots_env = getenv("HALO_DOTS_FIRST") ? atoi(getenv("HALO_DOTS_FIRST")) : -1;  // development switch
+    const int dots_env = tuning().dots_first;  // development switch
     const bool dots_first = dots_env >= 0 ? dots_env != 0 : (st->nofold ? st->M : m) > ((size_t)1 << 16);
     auto launch_dots = [&]() -> int {
         hipStream_t saved = ctx->stream;
@@ -794,7 +845,7 @@ static int ipa_round_lr_points(halo_ipa *st, host::Fr dots[2], host::Point *Lp_o
             both.scalars[1] = st->d_FR;
             // half of each scalar array is zero: over a 2^16-point key 23 windows of 11 bits beat the table's 20 of 13 (measured,
             // medians of 13 opens on one box: 15.40 / 15.42 -> 15.23 / 15.37 ms; 10, 12 and 14 bits are worse, other key sizes keep the table)
-            static const bool hint_env = !(getenv("HALO_IPA_C_HINT") && atoi(getenv("HALO_IPA_C_HINT")) == 0);  // development switch
+            const bool hint_env = tuning().ipa_c_hint;  // development switch
             if (hint_env && st->M == ((size_t)1 << 16)) both.c_hint = 11;
             rc = msm_enqueue_batch(ctx, 0, st->G_src, both, true, st->M);
             if (rc) return rc;
@@ -957,7 +1008,7 @@ int halo_ipa_finish(halo_ipa *st, uint64_t U[12], uint64_t c[4]) {
         st->fold_pending = false;
     }
     int rc;
-    static const bool u_from_last_round = !(getenv("HALO_U_FROM_LAST_ROUND") && atoi(getenv("HALO_U_FROM_LAST_ROUND")) == 0);  // development switch
+    const bool u_from_last_round = tuning().u_from_last_round;  // development switch
     if (st->nofold && st->M > 1 && st->last_valid && st->last_folded && u_from_last_round && !st->last_c0.is_zero() && !st->last_c1.is_zero()) {
         // U = G_final[0] = sum_b s''[b] K[b] with s''[2t + u] = s[t] xi^u (the last fold): U = A + xi B, A / B = the sums of
         // s[t] K[2t] / s[t] K[2t + 1].  The last round had two coefficients left, so its MSMs were exactly L' = c1 A and
@@ -1113,10 +1164,6 @@ int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, lon
     if (launches) *launches = ctx->prof_merged[i].launches;
     return HALO_OK;
 }
-int halo_bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps) {
-    HALO_CTX(ctx);
-    return bench_fr_kernel(ctx, which, n, reps);
-}
 // ---- host steps of a sharded pcdl::open (halo-accumulation_amd/sharded.py) ---------------------
 int halo_open_start(const uint64_t C[12], const uint64_t z[4], const uint64_t *v_parts, size_t P, uint64_t v_out[4], uint64_t xi0[4],
                     uint64_t Hp_out[12]) {
@@ -1251,18 +1298,6 @@ int halo_open_tail(const uint64_t *recs, size_t P, const uint64_t Hp[12], const 
     return HALO_OK;
 }
 
-int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n_out) {
-    if (!xi || !out || !n_out) { set_error("glv_digits: null pointer"); return HALO_E_ARG; }
-    host::GlvDigits dg = host::glv_digits(host::Fr::load(xi));
-    for (int i = 0; i < 144; ++i) out[i] = i < dg.n ? dg.d[i] : 0;
-    *n_out = dg.n;
-    return HALO_OK;
-}
-int halo_test_fold_digits(const uint64_t s[4], int8_t out[44]) {
-    if (!s || !out) { set_error("fold_digits: null pointer"); return HALO_E_ARG; }
-    fold_digits_host(host::Fr::load(s), out);
-    return HALO_OK;
-}
 int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out) {
     HALO_CTX(ctx);
     if (!rng_state || (n && !d_out)) { set_error("rng_scalars: null pointer"); return HALO_E_ARG; }
@@ -1279,37 +1314,8 @@ int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]) {
     acc.store_normalized(out);
     return HALO_OK;
 }
-int halo_set_graphs(halo_ctx *ctx, int on) {
-    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
-    ctx->use_graphs = on != 0;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_graphs(sh, on);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
-int halo_set_ipa_switch(halo_ctx *ctx, size_t size) {
-    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
-    ctx->nofold_size = size;
-    return HALO_OK;
-}
-int halo_set_window_bits(halo_ctx *ctx, int c) {
-    if (!ctx || (c != 0 && (c < 4 || c > 16))) { set_error("window bits must be 0 or in [4, 16]"); return HALO_E_ARG; }
-    ctx->window_bits = c;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_window_bits(sh, c);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
 
-int halo_set_reduce_span(halo_ctx *ctx, int span) {
-    if (!ctx || span < 0 || span > 512 || (span & (span - 1))) { set_error("reduce span must be 0 or a power of two <= 512"); return HALO_E_ARG; }
-    ctx->reduce_span = span;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_reduce_span(sh, span);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
 
-int halo_set_sort_mode(halo_ctx *ctx, int mode) {
-    if (!ctx || mode < -1 || mode > 1) { set_error("sort mode must be -1 (automatic), 0 (one level) or 1 (two levels)"); return HALO_E_ARG; }
-    ctx->sort_two_level = mode;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_sort_mode(sh, mode);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
 int halo_set_table_mode(halo_ctx *ctx, int mode) {
     if (!ctx || mode < -1 || mode > 0) { set_error("table mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
     if (mode == 0 && ctx->d_table) {  // "no table memory": a table already built is released, not just left unused
@@ -1321,27 +1327,6 @@ int halo_set_table_mode(halo_ctx *ctx, int mode) {
     ctx->table_retry_at = 0;
     ctx->table_status = 0;
     for (halo_ctx *sh : ctx->shards) (void)halo_set_table_mode(sh, mode);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
-int halo_set_small_path(halo_ctx *ctx, int mode) {
-    if (!ctx || mode < -1 || mode > 0) { set_error("small path mode must be -1 (automatic) or 0 (never)"); return HALO_E_ARG; }
-    ctx->small_path = mode;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_small_path(sh, mode);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
-int halo_set_batch_verify(halo_ctx *ctx, int on) {
-    if (!ctx) { set_error("null context"); return HALO_E_ARG; }
-    ctx->batch_verify = on != 0;
-    return HALO_OK;
-}
-int halo_set_fold_levels(halo_ctx *ctx, int levels) {
-    if (!ctx || (levels != 1 && levels != 2)) { set_error("fold levels must be 1 or 2"); return HALO_E_ARG; }
-    ctx->fold_levels = levels;
-    return HALO_OK;
-}
-int halo_set_fold_async(halo_ctx *ctx, int mode) {
-    if (!ctx || mode < -1 || mode > 1) { set_error("fold async mode must be -1 (automatic), 0 (never) or 1 (wherever possible)"); return HALO_E_ARG; }
-    ctx->fold_async = mode;
     return HALO_OK;
 }
 int halo_set_fold_table(halo_ctx *ctx, int mode) {
@@ -1363,21 +1348,13 @@ namespace {
 struct DeviceBudget { size_t budget = 0, used = 0; bool known = false; };
 std::mutex g_budget_mu;
 DeviceBudget g_budget[64];
-// HALO_MEMORY_BUDGET=<bytes>[K|M|G] in the environment replaces the default (for hosts that cannot call the setter: the Rust shim)
-size_t parse_bytes(const char *e) {
-    char *rest = nullptr;
-    double v = strtod(e, &rest);
-    if (rest && (*rest == 'K' || *rest == 'k')) v *= 1024.0;
-    else if (rest && (*rest == 'M' || *rest == 'm')) v *= 1024.0 * 1024.0;
-    else if (rest && (*rest == 'G' || *rest == 'g')) v *= 1024.0 * 1024.0 * 1024.0;
-    return v > 0 ? (size_t)v : 0;
-}
+// HALO_MEMORY_BUDGET=<bytes>[K|M|G] in the environment (read by tuning()) replaces the default (for hosts that cannot call the setter: the Rust shim)
 DeviceBudget &budget_of(int device) {  // (g_budget_mu held; the device is current)
     DeviceBudget &b = g_budget[device & 63];
     if (!b.known) {
         b.known = true;
         size_t free_b = 0, total = 0;
-        if (const char *e = getenv("HALO_MEMORY_BUDGET")) b.budget = parse_bytes(e);
+        if (tuning().memory_budget_set) b.budget = tuning().memory_budget;
         else if (hipMemGetInfo(&free_b, &total) == hipSuccess) b.budget = total / 6;  // 48 GB of an MI355X's 288
         else (void)hipGetLastError();
     }
@@ -1442,40 +1419,7 @@ size_t halo_ctx_info(const halo_ctx *ctx, int what) {
     if (what == 6) return ctx->table_mode == 0 ? 5 : ctx->d_table ? 2 : (size_t)ctx->table_status;
     return 0;
 }
-int halo_set_task_len(halo_ctx *ctx, int len) {
-    if (!ctx || !(len == 0 || len == 8 || len == 16 || len == 32 || len == 64)) { set_error("task length must be 0, 8, 16, 32 or 64"); return HALO_E_ARG; }
-    ctx->task_len = len;
-    for (halo_ctx *sh : ctx->shards) (void)halo_set_task_len(sh, len);  // a multi-device context: its shards run the MSMs
-    return HALO_OK;
-}
 
 // ------------------------------------------------------------------ primitive hooks
-int halo_test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
-    HALO_CTX(ctx);
-    if (n > (ctx->n < 64 ? 64 : ctx->n)) { set_error("test_field_op: n exceeds context size"); return HALO_E_ARG; }
-    int rc = upload(ctx, ctx->d_tmp_a, a, n * 4);
-    if (!rc && b) rc = upload(ctx, ctx->d_tmp_b, b, n * 4);
-    if (rc) return rc;
-    rc = test_field_op(ctx, field, op, ctx->d_tmp_a, b ? ctx->d_tmp_b : nullptr, n, ctx->d_tmp_a + 4 * n);
-    if (rc) return rc;
-    return download(ctx, out, ctx->d_tmp_a + 4 * n, n * 4);
-}
-int halo_test_point_op(halo_ctx *ctx, int op, const uint64_t *a_jac, const uint64_t *b, size_t n, uint64_t *out_jac) {
-    HALO_CTX(ctx);
-    if (n > (ctx->n < 64 ? 64 : ctx->n) / 2) { set_error("test_point_op: n exceeds half the context size"); return HALO_E_ARG; }
-    size_t bw = (op == 0 || op == 4 || op == 6) ? 12 : (op == 1 ? 8 : 4);
-    int rc = upload(ctx, ctx->d_tmp_a, a_jac, n * 12);
-    if (!rc && b && op != 2 && op != 5) rc = upload(ctx, ctx->d_tmp_b, b, n * bw);
-    if (rc) return rc;
-    // output goes to the upper half of d_tmp_a? keep it simple: a dedicated allocation
-    uint64_t *d_out = nullptr;
-    HALO_HIP(hipMalloc(&d_out, n * 96));
-    rc = test_point_op(ctx, op, ctx->d_tmp_a, ctx->d_tmp_b, n, d_out);
-    if (!rc) rc = download(ctx, out_jac, d_out, n * 12);
-    (void)hipFree(d_out);
-    if (rc) return rc;
-    for (size_t i = 0; i < n; ++i) host::Point::load(out_jac + 12 * i).store_normalized(out_jac + 12 * i);
-    return HALO_OK;
-}
 
 }  // extern "C"

@@ -269,7 +269,7 @@ static void foldtab_unclaim(halo_ctx *ctx) {
 
 // the table over [n/4, n) of the context's key, built in slices through a temporary of at most ~4 GiB
 static hipError_t foldtab_alloc(size_t n, uint32_t **tab, uint32_t **tmp) {
-    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(tab, foldtab_table_bytes(n));
+    hipError_t e = dev_hooks().table_fail ? hipErrorOutOfMemory : hipMalloc(tab, foldtab_table_bytes(n));
     if (e == hipSuccess) e = hipMalloc(tmp, foldtab_tmp_bytes(n));
     return e;
 }
@@ -358,9 +358,17 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
     if (d_src != ctx->d_bases || 4 * m != ctx->n || m < 16 || d_dst == d_src || ctx->fold_table_mode == 0) return 0;
     if (!ctx->d_foldtab) (void)foldtab_adopt(ctx);
     if (!ctx->d_foldtab) {
-        // mode 1: at the first full-size open; default (-1): the memory is requested on a helper thread at the first full-size
-        // open and the table is built at the first later open that finds it there (a context that opens once never waits)
+        // mode 1: at the next full-size open.  Default (-1): the table costs as much as 64 opens save (0.17 s of kernels for 2.6 ms
+        // each) and 35 GB, so a key must have shown that it is opened again and again before it gets one: from its K-th full-size
+        // open on (K = tuning().fold_table_after = 8, counted over all contexts of the key) the memory is requested on a helper
+        // thread and the table is built at the first later open that finds it there.  A caller with a handful of opens never pays
+        // for, and never reserves memory for, a table it cannot amortise; a caller that knows better says halo_set_fold_table(ctx, 1).
         ctx->foldtab_opens++;
+        long key_opens;
+        {
+            std::lock_guard<std::mutex> lk(ctx->share->mu);
+            key_opens = ++ctx->share->full_opens;
+        }
         // (automatic mode also stops at 2^21 points: 71 GB; larger keys on request only)
         int rc;
         if (ctx->fold_table_mode == 1) {
@@ -385,7 +393,9 @@ int fold_points4_tab(halo_ctx *ctx, const uint32_t *d_src, uint32_t *d_dst, size
         } else {
             if (!(ctx->fold_table_mode < 0 && ctx->n >= ((size_t)1 << 18) && ctx->n <= ((size_t)1 << 21))) return 0;
             int st = ctx->foldtab_alloc_state.load(std::memory_order_acquire);
-            if (st == 0) {  // first full-size open: ask for the memory in the background; this open takes the generic kernel
+            if (st == 0) {  // the key has earned its table: ask for the memory in the background; this open takes the generic kernel
+                const int K = tuning().fold_table_after;
+                if (K <= 0 || key_opens < (long)K) return 0;
                 if (ctx->foldtab_opens < ctx->foldtab_retry_at) return 0;
                 if (!foldtab_claim(ctx)) return 0;  // (a clone is at it: the generic kernel this time)
                 if (!foldtab_reserve(ctx)) { foldtab_unclaim(ctx); foldtab_later(ctx, 3, "over the budget for optional memory, halo_set_memory_budget"); return 0; }

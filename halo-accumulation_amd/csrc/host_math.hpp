@@ -16,6 +16,7 @@
 
 namespace halo {
 namespace host {
+inline bool g_inv_fermat = false;  // set from tuning() when a context is created (development switch)
 
 using u64 = uint64_t;
 using u128 = unsigned __int128;
@@ -296,8 +297,7 @@ struct Fp {
     // The limbs hold a = x R: the plain integer inverse of a is x^-1 R^-1, and one Montgomery product with R^3 makes it x^-1 R.
     Fp inv() const {
         if (is_zero()) return *this;
-        static const bool use_fermat = getenv("HALO_HOST_INV_FERMAT") != nullptr;  // development switch for A/B runs
-        if (use_fermat) return inv_fermat();
+        if (g_inv_fermat) return inv_fermat();  // development switch for A/B runs (HALO_HOST_INV_FERMAT, csrc/tuning.hpp)
         static const Fp R3 = Fp{{P::R2[0], P::R2[1], P::R2[2], P::R2[3]}} * Fp{{P::R2[0], P::R2[1], P::R2[2], P::R2[3]}};
         Fp r;
         modinv::inverse(l, P::M, r.l);

@@ -17,6 +17,7 @@
 
 #include "../../include/halo_accumulation.h"
 #include "host_math.hpp"
+#include "tuning.hpp"
 
 namespace halo {
 
@@ -48,7 +49,6 @@ struct Profiler {
     void collect();  // needs the stream to be idle
 };
 
-inline bool debug_trace() { static const bool on = getenv("HALO_TRACE") != nullptr; return on; }
 // k_msm_accumulate, k_smsm_accumulate, k_fold_points, k_fold_points4
 inline bool prof_is_dominant(const char *name) {
     return name[2] == 'm' ? name[6] == 'a' : name[2] == 's' ? name[7] == 'a' : (name[2] == 'f' && name[7] == 'p');
@@ -99,6 +99,9 @@ struct MsmBatch {
     // free, r < 2^255 -- says which of two bucket sets point i goes to.  One recode / sort / bucket kernel / window-sum pass for
     // both; results as for a batch of two (msm_wait(.., 2), msm_combine_member 0 / 1).  The IPA's L and R over the full key.
     bool tagged = false;
+    // A stretch of a LARGER sum over the context's key (halo_msm with host scalars: the stretches run on different slots, each
+    // behind the copy of its own scalars): takes the c = 20 table plan although n is below its usual 2^20 points.
+    bool sub = false;
 };
 inline int msm_outputs(const MsmBatch &m) { return m.tagged ? 2 : m.count; }
 MsmPlan msm_plan(size_t n, int forced_c);
@@ -135,7 +138,7 @@ struct MsmWorkspace {
         int mont = 0, c = 0, span = 0;
         bool operator==(const GraphKey &o) const {
             if (!(bases == o.bases && n == o.n && mont == o.mont && c == o.c && span == o.span && members.count == o.members.count &&
-                  members.part == o.members.part && members.parts == o.members.parts && members.c_hint == o.members.c_hint && members.tagged == o.members.tagged))
+                  members.part == o.members.part && members.parts == o.members.parts && members.c_hint == o.members.c_hint && members.tagged == o.members.tagged && members.sub == o.members.sub))
                 return false;
             for (int b = 0; b < members.count; ++b)
                 if (members.scalars[b] != o.members.scalars[b] || members.base_off[b] != o.members.base_off[b]) return false;
@@ -266,6 +269,7 @@ struct KeyShare {
     size_t foldtab_bytes = 0;
     double foldtab_build_ms = 0;
     bool table_busy = false, foldtab_busy = false;
+    long full_opens = 0;     // full-size opens over this key by any of its contexts while no fold table existed (the automatic mode builds from tuning().fold_table_after on)
     size_t budget_held = 0;  // bytes of optional memory reserved for this key (abi.hip table_budget_*)
 };
 
@@ -292,7 +296,7 @@ struct halo_ctx {
     bool use_graphs = true;                // replay cached hipGraphs for repeated MSM shapes
     size_t nofold_size = (size_t)1 << 14;  // key size at which the IPA stops folding G (0/1 = never)
     bool batch_verify = true;              // succinct checks of >= 64 instances in two device launches (else a host thread pool)
-    int fold_table_mode = -1;              // comb table for the first fold of an open (foldtab.hip): -1 memory requested at the first full-size open, built at the first later one that finds it; 1 at once; 0 never
+    int fold_table_mode = -1;              // comb table for the first fold of an open (foldtab.hip): -1 after tuning().fold_table_after (8) full-size opens over the key -- memory requested on a helper thread, built at the first later open that finds it; 1 at the next open; 0 never
     uint32_t *d_foldtab = nullptr;         // E[w][d][i - n/4] = d 64^w G_i, 64-byte affine entries
     size_t foldtab_bytes = 0;
     double foldtab_build_ms = 0;
@@ -501,3 +505,11 @@ int upload_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words
 int download_words(halo_ctx *ctx, uint64_t *dst, const uint64_t *src, size_t words);
 
 }  // namespace halo
+
+// guard used by every entry point that touches the device
+#define HALO_CTX(ctx)                                                 \
+    do {                                                              \
+        if (!(ctx)) { halo::set_error("null context"); return HALO_E_ARG; } \
+        hipError_t _e = hipSetDevice((ctx)->device);                  \
+        if (_e != hipSuccess) return halo::hip_fail(_e, "hipSetDevice"); \
+    } while (0)

@@ -381,14 +381,7 @@ constexpr int POLY_EVAL_E = 16;  // coefficients per lane of k_poly_eval_partial
 static int pow_chain_len(size_t n, int best) {
     // development override: a power of two in [4, 64] or it is ignored -- k_h_coeffs relies on a chain length that is a power of
     // two (its mid * high factor is wave-uniform and changes every fourth step): another value would give wrong coefficients
-    static const int forced = [] {
-        int v = getenv("HALO_POW_E") ? atoi(getenv("HALO_POW_E")) : 0;
-        if (v != 0 && (v < 4 || v > 64 || (v & (v - 1)) != 0)) {
-            fprintf(stderr, "[halo] HALO_POW_E=%d ignored: the chain length must be a power of two in [4, 64]\n", v);
-            v = 0;
-        }
-        return v;
-    }();
+    const int forced = tuning().pow_e;  // (validated there)
     if (forced > 0) return forced;
     int e = best;
     while (e > 4 && n / (64 * (size_t)e) < 1024) e >>= 1;  // small inputs: at least a wave per SIMD
@@ -729,7 +722,7 @@ static unsigned reduce_blocks(size_t work_items) {
 
 // two elements per lane and trip, at most 512 blocks (two waves per SIMD): the lanes of a large dot product run several trips
 static unsigned dot_blocks(size_t m) {
-    static const size_t cap_env = getenv("HALO_DOT_BLOCKS") ? (size_t)atoi(getenv("HALO_DOT_BLOCKS")) : 0;  // development override
+    const size_t cap_env = tuning().dot_blocks > 0 ? (size_t)tuning().dot_blocks : 0;  // development override
     size_t nb = ((m + 1) / 2 + 255) / 256, cap = cap_env ? cap_env : 512;
     if (nb > cap) nb = cap;
     if (nb == 0) nb = 1;

@@ -41,7 +41,7 @@ MsmPlan msm_plan(size_t n, int forced_c) {
     static const int table[] = {/*lg 10*/ 8, 8, 8, 10, 10, 13, 13, 15, 15, /*lg 19*/ 15};
     int c = forced_c > 0 ? forced_c : (lg >= 20 ? 16 : lg >= 10 ? table[lg - 10] : lg - 2);
     // development override, e.g. HALO_PLAN="16:12,15:12": window bits for MSMs of 2^lg <= n < 2^(lg+1) points
-    static const char *plan_env = getenv("HALO_PLAN");
+    const char *plan_env = tuning().plan;
     if (plan_env && forced_c <= 0) {
         for (const char *q = plan_env; *q;) {
             int l = atoi(q);
@@ -1333,127 +1333,6 @@ __global__ __launch_bounds__(256) void k_urs(const uint32_t *__restrict__ table,
     });
 }
 
-// ------------------------------------------------------------------------------ test hooks
-template <class F>
-__global__ __launch_bounds__(256) void k_test_field(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Fe x = fe_load(a + 4 * (size_t)i);
-    Fe y = b ? fe_load(b + 4 * (size_t)i) : fe_zero();
-    Fe r;
-    switch (op) {
-        case 0: r = fe_mul<F>(x, y); break;
-        case 1: r = fe_add<F>(x, y); break;
-        case 2: r = fe_sub<F>(x, y); break;
-        case 3: r = fe_is_zero(x) ? fe_zero() : fe_inv<F>(x); break;
-        case 4: r = fe_from_mont<F>(x); break;
-        default: r = fe_to_mont<F>(x); break;
-    }
-    fe_store(out + 4 * (size_t)i, r);
-}
-// the same operations through the native radix-2^29 field (Fq only): in/out in arkworks words
-__global__ __launch_bounds__(256) void k_test_field29(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Fq<2> x = fq_from_words(fe_load(a + 4 * (size_t)i));
-    Fq<2> y = b ? fq_from_words(fe_load(b + 4 * (size_t)i)) : fq_zero<2>();
-    Fe r;
-    switch (op) {
-        case 0: r = fq_to_words(fq_mul(x, y)); break;
-        case 1: r = fq_to_words(fq_add(x, y)); break;
-        case 2: r = fq_to_words(fq_sub<2>(x, y)); break;
-        case 3: r = fq_is_zero_modp(x) ? fe_zero() : fq_to_words(fq_inv(x)); break;
-        case 6: r = fq_to_words(fq_sqr(x)); break;
-        case 7: r = fq_to_words(fq_muls<4>(fq_muls<3>(fq_add(x, y)))); break;  // 12 (x + y), lazy chain
-        case 8: r = fq_to_words(fq_tighten(fq_sub_sub2(fq_muls<4>(x), y, x))); break;  // 2x - y
-        default: r = fq_to_words(x); break;                                            // round trip
-    }
-    fe_store(out + 4 * (size_t)i, r);
-}
-HALO_DEV bool aff_same(const AffN &a, const AffN &b) {
-    if (aff_is_inf(a) || aff_is_inf(b)) return aff_is_inf(a) && aff_is_inf(b);
-    return fq_eq_modp(a.x, b.x) && fq_eq_modp(a.y, b.y);
-}
-__global__ __launch_bounds__(256) void k_test_point(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    JacN p = jac_from_words(a + 12 * (size_t)i);
-    uint64_t *o = out + 12 * (size_t)i;
-    if (op == 0) {
-        XyzzN x = jac_to_xyzz(p);
-        xyzz_add(x, jac_to_xyzz(jac_from_words(b + 12 * (size_t)i)));
-        xyzz_store_jac_words(o, x);
-    } else if (op == 1) {
-        AffN q = aff_from_words(b + 8 * (size_t)i);
-        XyzzN x = jac_to_xyzz(p);
-        xyzz_madd(x, q);
-        JacN r2 = jac_madd(p, q);  // both mixed-add forms must agree; disagreement poisons the output
-        JacN x1; x1.x = fq_widen<8>(fq_mul(x.x, fq_sqr(x.zz))); x1.y = fq_widen<8>(fq_mul(x.y, fq_sqr(x.zzz))); x1.z = fq_widen<4>(x.zzz);
-        if (xyzz_is_inf(x)) x1 = jac_inf();
-        if (aff_same(jac_to_aff(x1), jac_to_aff(r2))) jac_store_words(o, r2);
-        else { AffN bad; bad.x = fq_widen<2>(fq_one()); bad.y = bad.x; jac_store_words(o, jac_from_aff(bad)); }
-    } else if (op == 2) {
-        JacN r1 = jac_dbl(p);
-        XyzzN x = xyzz_dbl(jac_to_xyzz(p));
-        JacN x1; x1.x = fq_widen<8>(fq_mul(x.x, fq_sqr(x.zz))); x1.y = fq_widen<8>(fq_mul(x.y, fq_sqr(x.zzz))); x1.z = fq_widen<4>(x.zzz);
-        if (xyzz_is_inf(x)) x1 = jac_inf();
-        if (aff_same(jac_to_aff(r1), jac_to_aff(x1))) jac_store_words(o, r1);
-        else { AffN bad; bad.x = fq_widen<2>(fq_one()); bad.y = bad.x; jac_store_words(o, jac_from_aff(bad)); }
-    } else {
-        // p * scalar (Montgomery Fr), MSB-first double-and-add on the affine form of p
-        Fe k = fe_from_mont<FrCfg>(fe_load(b + 4 * (size_t)i));
-        AffN pa = jac_to_aff(p);
-        JacN acc = jac_inf();
-#pragma unroll 1
-        for (int limb = 7; limb >= 0; limb--) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) word = (q == limb) ? k.v[q] : word;
-#pragma unroll 1
-            for (int bit = 31; bit >= 0; bit--) {
-                acc = jac_dbl(acc);
-                if ((word >> bit) & 1u) acc = jac_madd(acc, pa);
-            }
-        }
-        jac_store_words(o, acc);
-    }
-}
-
-// the quad-parallel forms of curve_quad.hpp, one point per 4 lanes: op 4 = a + b (XYZZ add), op 5 = 2a, op 6 = a + b where
-// every fourth pair is replaced by (a, a) so that general additions and doublings share a wave
-__global__ __launch_bounds__(256) void k_test_point_quad(int op, const uint64_t *a, const uint64_t *b, uint32_t n, uint64_t *out) {
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t i = t >> 2;
-    int ql = (int)(t & 3);
-    bool live = i < n;
-    if (!live) i = n - 1;  // keep every lane of the wave busy: the quad forms need whole quads
-    XyzzN x = jac_to_xyzz(jac_from_words(a + 12 * (size_t)i));
-    XyzzN y = jac_to_xyzz(jac_from_words((op == 5 || (op == 6 && (i & 3) == 3) ? a : b) + 12 * (size_t)i));
-    if (op == 5) x = xyzz_dbl_quad(x, ql);
-    else xyzz_add_quad(x, y, ql);
-    if (live && ql == 0) xyzz_store_jac_words(out + 12 * (size_t)i, x);
-}
-
-int test_field_op(halo_ctx *ctx, int field, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (field == 2) HALO_LAUNCH(ctx, "k_test_field29", k_test_field29, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
-    else if (field == 0) HALO_LAUNCH(ctx, "k_test_field", k_test_field<FqCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
-    else HALO_LAUNCH(ctx, "k_test_field", k_test_field<FrCfg>, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
-    HALO_HIP(hipGetLastError());
-    return HALO_OK;
-}
-int test_point_op(halo_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out) {
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (op >= 4) {
-        HALO_LAUNCH(ctx, "k_test_point_quad", k_test_point_quad, dim3((unsigned)((4 * n + 255) / 256)), block, 0, op, d_a, d_b, (uint32_t)n, d_out);
-        HALO_HIP(hipGetLastError());
-        return HALO_OK;
-    }
-    HALO_LAUNCH(ctx, "k_test_point", k_test_point, grid, block, 0, op, d_a, d_b, (uint32_t)n, d_out);
-    HALO_HIP(hipGetLastError());
-    return HALO_OK;
-}
-
 int batch_to_affine(halo_ctx *ctx, const uint64_t *d_jac, size_t n, uint32_t *d_out) {
     if (n == 0) return HALO_OK;
     dim3 grid((unsigned)(((n + TBL_E - 1) / TBL_E + 255) / 256)), block(256);
@@ -1643,10 +1522,10 @@ struct StreamGuard {  // the launch macro uses ctx->stream
 };
 
 static uint32_t msm_kmax(const halo_ctx *ctx, size_t n) {
-    static const int small_env = getenv("HALO_SMSM_KMAX") ? atoi(getenv("HALO_SMSM_KMAX")) : 0;  // development override
+    const int small_env = tuning().smsm_kmax;  // development override
     if (ctx->task_len > 0) return (uint32_t)ctx->task_len;
     if (small_env > 0 && n <= ((size_t)1 << 16)) return (uint32_t)small_env;
-    static const int late_env = getenv("HALO_LATE_KMAX") ? atoi(getenv("HALO_LATE_KMAX")) : 0;  // development override
+    const int late_env = tuning().late_kmax;  // development override
     if (n <= ((size_t)1 << 14)) return late_env > 0 ? (uint32_t)late_env : 8u;  // the IPA's late rounds: the chain is the round's latency (measured: 16 -> 8: -0.15 ms per open)
     return n >= ((size_t)1 << 18) ? KMAX : 16u;
 }
@@ -1745,7 +1624,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     // piece k + 1 sorts and accumulates while piece k's window sums -- latency chains on a few hundred waves -- finish.
     int partner = -1;
     if (ctx->may_borrow > 0 && members.count == 1 && ctx->d_table && ctx->tbl.c == 20 && n > TBL_PIECE && table_eligible(ctx, d_bases, members, n) &&
-        !(getenv("HALO_PIECE_ALTERNATE") && atoi(getenv("HALO_PIECE_ALTERNATE")) == 0)) {
+        tuning().piece_alternate) {
         int cand = slot ^ 1;
         if (!ctx->wss[cand].in_flight) {
             if (!ctx->wss[cand].d_counts || ctx->wss[cand].cap_n < ws.cap_n) {
@@ -1777,10 +1656,8 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         }
         ws.graph_epoch = ctx->alloc_epoch;
     }
-    static const int cache_n = [] {  // development switch: HALO_GRAPH_CACHE=1 is the single graph per slot of rounds 1-3
-        int v = getenv("HALO_GRAPH_CACHE") ? atoi(getenv("HALO_GRAPH_CACHE")) : MsmWorkspace::GRAPHS;
-        return v < 1 ? 1 : (v > MsmWorkspace::GRAPHS ? MsmWorkspace::GRAPHS : v);
-    }();
+    const int cache_n = tuning().graph_cache;  // development switch: HALO_GRAPH_CACHE=1 is the single graph per slot of rounds 1-3
+    static_assert(MsmWorkspace::GRAPHS == 8, "tuning.hip clamps HALO_GRAPH_CACHE to 8");
     MsmWorkspace::CachedGraph *hit = nullptr;
     for (int k = 0; k < cache_n; ++k)
         if (ws.graphs[k].exec && key == ws.graphs[k].key) hit = &ws.graphs[k];
@@ -1803,7 +1680,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     if (capture) HALO_HIP(hipStreamBeginCapture(ctx->streams[slot], hipStreamCaptureModeRelaxed));
     // The launch's last kernel publishes its sums itself (smsm.hip publish(): pinned buffer + pinned counter) unless the event
     // profiler brackets every launch or HALO_DIRECT_RESULTS=0 asks for the copy + stream wait of rounds 1-3 (development switch).
-    static const bool direct = !(getenv("HALO_DIRECT_RESULTS") && atoi(getenv("HALO_DIRECT_RESULTS")) == 0);
+    const bool direct = tuning().direct_results;
     ctx->sink_done = direct && !ctx->prof.on ? ws.h_done : nullptr;
     ctx->sink_publishers = 0;
     int rc = msm_enqueue_launches(ctx, ws, d_bases, members, mont, n, partner);
@@ -1878,7 +1755,7 @@ static int table_build(halo_ctx *ctx) {
     // built into a local pointer and published (d_table + tbl together) only after the last step has succeeded: a
     // half-built table is never visible to table_eligible / tmsm_enqueue_piece
     uint32_t *tbl = nullptr;
-    hipError_t e = getenv("HALO_TEST_TABLE_FAIL") ? hipErrorOutOfMemory : hipMalloc(&tbl, bytes);  // (test hook: the failure path)
+    hipError_t e = dev_hooks().table_fail ? hipErrorOutOfMemory : hipMalloc(&tbl, bytes);  // (development library's hook: the failure path)
     if (e == hipSuccess) {
         if (debug_trace()) fprintf(stderr, "[halo] table ctx=%p c=%d [%p, +%zu)\n", (void *)ctx, tp.c, (void *)tbl, bytes);
         e = hipMemcpyAsync(tbl, ctx->d_bases, n * 128, hipMemcpyDeviceToDevice, ctx->stream);
@@ -1911,7 +1788,7 @@ static int table_build(halo_ctx *ctx) {
 // A tagged launch (MsmBatch::tagged) has no table-free form: the caller asks first and keeps its two plain launches otherwise
 // (no table yet -- the first MSM over the key builds it --, table mode off, a forced window size, the small-key plan).
 bool msm_tagged_ready(const halo_ctx *ctx, const uint32_t *d_bases, size_t n) {
-    static const bool off = getenv("HALO_TAGGED") && atoi(getenv("HALO_TAGGED")) == 0;  // development switch: never
+    const bool off = !tuning().tagged;  // development switch: never
     if (off || !ctx->d_table || ctx->tbl.c != 20) return false;
     MsmBatch one;
     one.tagged = true;
@@ -1958,14 +1835,14 @@ static bool table_eligible(const halo_ctx *ctx, const uint32_t *d_bases, const M
             if (members.base_off[b] != members.base_off[0]) return false;
     }
     size_t least = tp.c == 20 ? ((size_t)1 << 20) : ((size_t)1 << 17);
-    if (ctx->n < least || n < least || (tp.c != 20 && 2 * n < ctx->n) || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
+    if (ctx->n < least || (n < least && !(members.sub && tp.c == 20 && n >= 4096)) || (tp.c != 20 && 2 * n < ctx->n) || n % 4 != 0 || (size_t)tp.W * ctx->n >= ((size_t)1 << 31)) return false;
     return d_bases >= ctx->d_bases && d_bases + AFF_STRIDE * n <= ctx->d_bases + AFF_STRIDE * ctx->n;
 }
 static int tmsm_enqueue_piece(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, const MsmBatch &members, size_t soff, bool mont, size_t n, int piece,
                               uint64_t *h_dst);
 // the shape of the row / column window sums (k_msm_reduce_rc) for a launch of `sets` bucket sets of B buckets each; per = 0: none
 static RcShape table_rc_shape(int c, uint32_t B, uint32_t sets) {
-    static const bool off = getenv("HALO_REDUCE_RC") && atoi(getenv("HALO_REDUCE_RC")) == 0;  // development switch: the older form
+    const bool off = !tuning().reduce_rc;  // development switch: the older form
     RcShape r;
     if (off) return r;
     if (c == 20 && (sets == 1 || sets == 2) && B == (1u << 19)) { r.lg_rows = 9; r.lg_cols = 10; r.per = 16; }  // (2 sets: a tagged launch, 2048 waves)
@@ -2218,7 +2095,7 @@ int msm_enqueue_launches(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_base
     {
         // no more waves than SIMDs (one wave each): a SIMD that holds two runs both chains at about half speed and the kernel
         // waits for it (development switch HALO_REDUCE1_WAVES, 0 = off)
-        static const int waves_env = getenv("HALO_REDUCE1_WAVES") ? atoi(getenv("HALO_REDUCE1_WAVES")) : 1024;
+        const int waves_env = tuning().reduce1_waves;
         while (waves_env > 0 && p.B > 64 && (size_t)Wt * nseg > (size_t)waves_env && nseg > 1 && L < 64) { L <<= 1; nseg >>= 1; }
     }
     if (ctx->reduce_span > 0 && p.B > 64) {

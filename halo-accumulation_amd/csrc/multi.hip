@@ -98,7 +98,7 @@ int multi_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *h
         // (no early return in here: whatever has been enqueued on other shards is drained below if this one fails)
         const uint64_t *src = dev_scalars + 4 * (a - off);
         hipError_t e = hipSetDevice(s->device);
-        const bool staged = src_dev != s->device || getenv("HALO_TEST_FORCE_PEER_COPY");  // (test hook: the copy path on a one-GPU box)
+        const bool staged = src_dev != s->device || dev_hooks().force_peer_copy;  // (development library's hook: the copy path on a one-GPU box)
         if (e == hipSuccess && staged) {  // the scalars live on another GPU: peer copy on this shard's stream, in front of its launches
             if (!s->d_slot_scalars[slot]) {
                 alloc_epoch_bump(s);
@@ -178,7 +178,7 @@ int multi_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const MsmBa
         for (int m = 0; m < members.count && e == hipSuccess; ++m) {
             const uint64_t *src = members.scalars[m] + 4 * (a - off);
             int src_dev = device_of(src, ctx->device);
-            if (src_dev != s->device || getenv("HALO_TEST_FORCE_PEER_COPY")) {  // (as multi_begin: peer copy in front of the launches)
+            if (src_dev != s->device || dev_hooks().force_peer_copy) {  // (as multi_begin: peer copy in front of the launches)
                 size_t need = (size_t)members.count * (s->n < 64 ? 64 : s->n) * 32;
                 if (s->batch_scalars_bytes[slot] < need) {
                     alloc_epoch_bump(s);

@@ -710,18 +710,16 @@ int halo_pcdl_check_partial(halo_ctx *ctx, const uint64_t C[12], size_t d, const
 // all-gather its peers never enter.  (A collective that itself fails -- the callback returns non-zero -- is the caller's
 // fabric failing: the call returns HALO_E_ARG on the ranks that see it and the caller must abort its process group.)
 namespace {
-// HALO_TEST_SHARD_FAIL="<offset>:<step>": the rank with this offset fails locally (HALO_E_DEVICE) before collective number
-// <step> of a sharded open (0 = the share of p(z), 1.. = the rounds, then the tail), or "<offset>:check" in a sharded check
-// -- the test hook of tests/test_sharded_gloo.py and tests/test_gpu_pcdl_acc.py for the failure path above
+// The development library's hooks "shard_fail_rank" / "shard_fail_at" (tuning.hpp DevHooks; never the environment): the rank with
+// that offset fails locally (HALO_E_DEVICE) before collective number `at` of a sharded open (0 = the share of p(z), 1.. = the
+// rounds, then the tail), or, with at = -2, in a sharded check -- what tests/test_sharded_gloo.py and
+// tests/test_gpu_pcdl_acc.py use to drive the failure path above
 int shard_test_failure(uint64_t offset, long step, bool in_check) {
-    const char *e = getenv("HALO_TEST_SHARD_FAIL");
-    if (!e) return HALO_OK;
-    char *rest = nullptr;
-    unsigned long long off = strtoull(e, &rest, 10);
-    if (!rest || *rest != ':' || off != offset) return HALO_OK;
-    bool hit = in_check ? std::strcmp(rest + 1, "check") == 0 : (std::strcmp(rest + 1, "check") != 0 && strtol(rest + 1, nullptr, 10) == step);
+    const DevHooks &h = dev_hooks();
+    if (h.shard_fail_rank < 0 || (uint64_t)h.shard_fail_rank != offset) return HALO_OK;
+    const bool hit = in_check ? h.shard_fail_at == -2 : (h.shard_fail_at >= 0 && (long)h.shard_fail_at == step);
     if (!hit) return HALO_OK;
-    set_error("sharded call: local failure injected by HALO_TEST_SHARD_FAIL");
+    set_error("sharded call: local failure injected by the development library's shard_fail hook");
     return HALO_E_DEVICE;
 }
 struct StatusGather {

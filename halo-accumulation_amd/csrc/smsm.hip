@@ -501,7 +501,7 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
                  uint32_t kmax) {
     const uint16_t *d_digits = reinterpret_cast<const uint16_t *>(ws.d_canon);
     // entries per wave task: 8 per lane where the launch is throughput-bound, 2 per lane for the latency-bound small ones
-    static const int wt_env = getenv("HALO_SMSM_WAVE_TASK") ? atoi(getenv("HALO_SMSM_WAVE_TASK")) : 0;  // development override
+    const int wt_env = tuning().smsm_wave_task;  // development override
     uint32_t wave_task = wt_env > 0 ? (uint32_t)wt_env : WAVE_TASK;
     // bucket ranges per window: enough blocks that one CU issues at most ~8K LDS atomics per pass
     uint32_t R = 1;
@@ -540,7 +540,7 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     {
         // ... and no more blocks than give every SIMD one wave (4 waves per block): with 1.6 waves per SIMD the SIMDs that
         // hold two ran every step of the chain at half speed, and the kernel waits for them
-        static const int waves_env = getenv("HALO_SMSM_WAVES") ? atoi(getenv("HALO_SMSM_WAVES")) : 1024;  // development switch (0: off)
+        const int waves_env = tuning().smsm_waves;  // development switch (0: off)
         while (waves_env > 0 && L < 64 && (size_t)Wt * ((p.B + 64 * L - 1) / (64 * L)) * 4 > (size_t)waves_env && (size_t)64 * L < p.B) L <<= 1;
     }
     if (ctx->reduce_span > 0) {
@@ -551,7 +551,7 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     int logL = 0, live_seg = 1;
     while ((1u << logL) < L) logL++;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
-    static const bool fused = getenv("HALO_SMSM_FUSED") && atoi(getenv("HALO_SMSM_FUSED")) != 0;
+    const bool fused = tuning().smsm_fused;
     // (one thread per window writes its sum: straight to the slot's pinned buffer when the launch publishes, see publish())
     uint64_t *out = ctx->sink_done ? ws.h_winsum : ws.d_winsum;
     if (fused || nseg == 1) {

@@ -291,7 +291,9 @@ int halo_instance_decode(const uint8_t *in, size_t len, uint64_t *instance_out, 
 int halo_accumulator_encode(const uint64_t *acc, uint8_t *out, size_t cap, size_t *len);
 int halo_accumulator_decode(const uint8_t *in, size_t len, uint64_t *acc_out, size_t cap_words, size_t *lg_n);
 
-/* ---- measurement hooks (bench.py) -------------------------------------------------------- */
+/* ---- measurement and resource policy ------------------------------------------------------ */
+/* (Experiment knobs, the primitive test hooks, halo_bench_fr_kernel and the fault injectors are NOT part of this library:
+ * include/halo_accumulation_dev.h, libhalo_hip_dev.so.  Environment switches: csrc/tuning.hpp) */
 /* on = 1: every kernel launch on this ctx is bracketed by hipEvents on the ctx stream;
  * on = 2: only the dominant kernels (k_msm_accumulate, k_fold_points); 0: off. */
 int halo_prof_enable(halo_ctx *ctx, int on);
@@ -299,38 +301,21 @@ int halo_prof_reset(halo_ctx *ctx);
 /* number of distinct kernels seen; name/total ms/launch count of entry i */
 int halo_prof_count(halo_ctx *ctx);
 int halo_prof_get(halo_ctx *ctx, int i, const char **name, double *total_ms, long *launches);
-/* `reps` back-to-back launches of one bandwidth-side Fr kernel over n elements of the context's scratch memory (no host
- * round trip in between): which = 0 k_powers, 1 k_poly_eval_partial, 2 k_dot2_partial (one pair of vectors), 3 k_dot2_partial
- * (the two pairs of an IPA round, m = n / 2), 4 k_h_coeffs, 5 k_fold_scalars (m = n / 2), 6 k_axpy.  For rocprofv3 / the
- * event profiler: steady-state kernel durations, the figures of bench.py's hbm_kernels block. */
-int halo_bench_fr_kernel(halo_ctx *ctx, int which, size_t n, int reps);
 /* n uniform scalars (Montgomery limbs) of the SplitMix64 stream, written to DEVICE memory: the
  * synthetic-input generator of the benchmarks (element i = draws 4i+1..4i+4 after *rng_state,
  * little-endian, reduced mod r); *rng_state advances as a sequential stream would */
 int halo_rng_scalars_dev(halo_ctx *ctx, uint64_t *rng_state, size_t n, void *d_out);
 /* sum of k Jacobian points in index order, on the host (combine step of the sharded MSM) */
 int halo_point_sum(const uint64_t *pts_jac, size_t k, uint64_t out[12]);
-/* replay cached hipGraphs of the MSM launch sequence when the same shape repeats (default on) */
-int halo_set_graphs(halo_ctx *ctx, int on);  /* also: environment HALO_GRAPHS=0 at context creation; HALO_TRACE=1 logs every launch */
-/* IPA tuning: key size at which halo_ipa_* stops folding G and switches to MSMs over the fixed
- * folded key (default 2^14; 0 or 1 = always fold).  Results are identical either way. */
-int halo_set_ipa_switch(halo_ctx *ctx, size_t size);
-/* IPA tuning: 2 (default) folds G every other round, two halvings at once with one shared doubling chain, the rounds in
- * between taking L, R from MSMs over the unfolded key; 1 folds G every round.  Results are identical either way. */
-int halo_set_fold_levels(halo_ctx *ctx, int levels);
-/* IPA tuning: a two-level fold of a key of at most 2^18 points (a latency chain on one wave per SIMD) can run on the context's
- * fourth stream BESIDE the next two rounds, which then take their L, R from the key it reads.  -1 (default): in opens of at
- * most 2^18 points, where it pays (9.3 -> 9.0 ms at 2^18; at 2^20 the rounds over the larger key lose more than the hidden
- * fold returns: 15.7 -> 16.4 ms); 0: every fold in line; 1: wherever possible.  Environment
- * HALO_FOLD_ASYNC=-1/0/1 at context creation.  Results are identical either way. */
-int halo_set_fold_async(halo_ctx *ctx, int mode);
 /* IPA tuning: comb table for the first fold of an open whose size is the context's key (E[w][d][i] = d 64^w G_i: 22
  * windows x 32 multiples x 64 bytes per point of the upper three quarters of the key = 33 KiB x n: 35.4 GB at n = 2^20, plus a
  * 4.6 GB temporary while it is built; ~0.2 s to build; the scalars are split with the curve's endomorphism, 2 x 22 entries per
- * scalar multiple; an open + check at 2^20 takes ~3 ms less with it).  -1 (default), contexts of 2^18 .. 2^21 points: the first
- * full-size open asks for the table's memory on a helper thread (40 GB at 2^20: 0.5 ms .. 2 s of hipMalloc depending on what
- * the driver has at hand) and the first later open that finds it there builds the table -- a prover chain (acc.rs:190-228)
- * opens twice per step, a single open never waits; 1: allocated and built at the first open; 0: never, a table already built
+ * scalar multiple; an open + check at 2^20 takes ~2.6 ms less with it, so the build pays for itself after ~64 opens).
+ * -1 (default), contexts of 2^18 .. 2^21 points: nothing happens during the first 7 full-size opens over a key (counted over
+ * the context and its clones) -- no memory is requested or reserved; the 8th asks for the table's memory on a helper thread
+ * (40 GB at 2^20: 0.5 ms .. 2 s of hipMalloc depending on what the driver has at hand) and the first later open that finds it
+ * there builds the table (environment HALO_FOLD_TABLE_AFTER=k replaces the 8; 0 = never automatically).  A caller that knows
+ * it will open many times says 1: allocated and built at the next full-size open; 0: never, a table already built
  * (or requested) is released.  The table is OPTIONAL memory and subject to halo_set_memory_budget below: over the budget the
  * generic fold kernel runs (halo_ctx_info(ctx, 5) says so) and the table is considered again later.  Results are identical. */
 int halo_set_fold_table(halo_ctx *ctx, int mode);
@@ -350,15 +335,6 @@ int halo_set_memory_budget(halo_ctx *ctx, size_t bytes);
  * that device), 5 = status of the fold table, 6 = status of the MSM table: 0 nothing yet, 1 memory requested, 2 built,
  * 3 over the budget, 4 allocation failed (tried again later), 5 switched off */
 size_t halo_ctx_info(const halo_ctx *ctx, int what);
-/* verifier tuning: 1 (default) = succinct checks of >= 64 instances on the device, 0 = always the host thread pool */
-int halo_set_batch_verify(halo_ctx *ctx, int on);
-/* MSM tuning: window bits (0 = automatic) */
-int halo_set_window_bits(halo_ctx *ctx, int c);
-/* MSM tuning: buckets per lane in the window-sum kernel (0 = automatic, else a power of two) */
-int halo_set_reduce_span(halo_ctx *ctx, int span);
-/* MSM tuning: bucket sort in one pass (0), in two (coarse runs, then a fine sort per run: 1, where the shape allows),
- * or chosen by size (-1, default: two levels from n = 2^17) */
-int halo_set_sort_mode(halo_ctx *ctx, int mode);
 /* MSM tuning: fixed-base tables.  -1 (default): an MSM of n >= 2^20 points over the context's own key uses the table
  * T[w][i] = 2^(20 w) G_i (13 x 128 bytes per point of the key, built on the first such MSM): 13 instead of 16 mixed
  * additions per point and one shared set of 2^19 buckets.  A context whose key has 2^17 .. 2^20 - 1 points builds
@@ -367,24 +343,7 @@ int halo_set_sort_mode(halo_ctx *ctx, int mode);
  * (budget, allocation) is not an error -- the table-free pipeline runs (halo_ctx_info(ctx, 6)) and the table is tried again
  * later.  Results are identical. */
 int halo_set_table_mode(halo_ctx *ctx, int mode);
-/* MSM tuning: the 4-launch pipeline for MSMs of up to 2^16 points (sort per window in LDS, quad-parallel window sums):
- * -1 automatic (default), 0 never (the general pipeline at every size).  Results are identical. */
-int halo_set_small_path(halo_ctx *ctx, int mode);
-/* MSM tuning: longest chain of mixed additions one lane runs in the bucket kernel (0 = automatic; 8, 16, 32, 64) */
-int halo_set_task_len(halo_ctx *ctx, int len);
 
-/* ---- primitive hooks used by the parity tests (elementwise over n) ----------------------- */
-/* host-only: base-2 expansion of the fold scalar over the Eisenstein units (host_math.hpp glv_digits):
- * out[i] = digit code of 2^i (0 none, 1..3 = +lambda^0..2, 4..6 = -lambda^0..2), *n = number of digits */
-int halo_test_glv_digits(const uint64_t xi[4], uint8_t out[144], int *n);
-/* host-only: the comb digits of the table fold (foldtab.hip): s = k1 + k2 lambda, out[0..22) = signed base-64 digits of k1
- * (each in [-32, 32]), out[22..44) = those of k2 */
-int halo_test_fold_digits(const uint64_t s[4], int8_t out[44]);
-int halo_test_field_op(halo_ctx *ctx, int field /*0 Fq, 1 Fr*/, int op /*0 mul,1 add,2 sub,3 inv,4 from_mont,5 to_mont*/,
-                       const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
-/* op 0: jacobian(a) + jacobian(b) via XYZZ add; 1: a + affine b (mixed); 2: double a; 3: a * scalar b (4 limbs);
- * 4, 5, 6: the quad-parallel forms (curve_quad.cuh): a + b, 2a, a + b with every fourth b replaced by a */
-int halo_test_point_op(halo_ctx *ctx, int op, const uint64_t *a_jac, const uint64_t *b, size_t n, uint64_t *out_jac);
 
 #ifdef __cplusplus
 }

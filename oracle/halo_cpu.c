@@ -19,11 +19,13 @@
  * (digest + samples in tests/golden/urs_kat.json), the Python big-int model
  * oracle/pallas_model.py, and the identities of the reference's own unit tests.
  */
+#define _POSIX_C_SOURCE 199309L
 #include "halo_cpu.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -37,7 +39,22 @@ typedef struct {
     u64 pm2[4];
 } field_t;
 
-static field_t FQ, FR;
+/* Both moduli and their Montgomery constants as compile-time constants: every field function below is `static inline` and is
+ * always called with &FQ or &FR, so the compiler folds the limbs in (p[2] = 0 and p[3] = 2^62 for both Pasta primes: two of
+ * the four reduction products of a row disappear).  ensure_init() recomputes every constant from p alone and refuses to run
+ * if one of them differs (field_selfcheck). */
+static const field_t FQ = {
+    {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0000000000000000ULL, 0x4000000000000000ULL},
+    0x992d30ecffffffffULL,
+    {{0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+    {{0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL}},
+    {0x992d30ecffffffffULL, 0x224698fc094cf91bULL, 0x0000000000000000ULL, 0x4000000000000000ULL}};
+static const field_t FR = {
+    {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0000000000000000ULL, 0x4000000000000000ULL},
+    0x8c46eb20ffffffffULL,
+    {{0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL}},
+    {{0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL}},
+    {0x8c46eb20ffffffffULL, 0x224698fc0994a8ddULL, 0x0000000000000000ULL, 0x4000000000000000ULL}};
 static int g_init = 0;
 static char g_err[256] = "";
 
@@ -45,41 +62,52 @@ const char *orc_last_error(void) { return g_err; }
 static int fail(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 
 /* ------------------------------------------------------------------ field */
+#define INL static inline __attribute__((always_inline))
 static int ge4(const u64 a[4], const u64 b[4]) {
     for (int i = 3; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; }
     return 1;
 }
-static u64 sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
+INL u64 sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
     u64 br = 0;
     for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - b[i] - br; r[i] = (u64)d; br = (u64)(d >> 64) & 1; }
     return br;
 }
-static u64 add4(u64 r[4], const u64 a[4], const u64 b[4]) {
+INL u64 add4(u64 r[4], const u64 a[4], const u64 b[4]) {
     u64 c = 0;
     for (int i = 0; i < 4; i++) { u128 s = (u128)a[i] + b[i] + c; r[i] = (u64)s; c = (u64)(s >> 64); }
     return c;
 }
-static void fe_add(fe *r, const fe *a, const fe *b, const field_t *F) {
-    u64 t[4]; u64 c = add4(t, a->l, b->l);
-    if (c || ge4(t, F->p)) sub4(t, t, F->p);
-    memcpy(r->l, t, 32);
+/* r = keep ? a : b, limb by limb, without a branch (a data-dependent branch here is mispredicted every other time: the sums
+ * of a point addition are uniform below 2 p) */
+INL void sel4(u64 r[4], u64 keep, const u64 a[4], const u64 b[4]) {
+    const u64 m = (u64)0 - keep;
+    for (int i = 0; i < 4; i++) r[i] = (a[i] & m) | (b[i] & ~m);
 }
-static void fe_sub(fe *r, const fe *a, const fe *b, const field_t *F) {
-    u64 t[4];
-    if (sub4(t, a->l, b->l)) add4(t, t, F->p);
-    memcpy(r->l, t, 32);
+/* ark-ff 0.5 Fp::add_assign: a + b, minus p if that is not below p (both moduli < 2^255: the sum has no fifth word) */
+INL void fe_add(fe *r, const fe *a, const fe *b, const field_t *F) {
+    u64 t[4], s[4];
+    add4(t, a->l, b->l);
+    const u64 below = sub4(s, t, F->p);
+    sel4(r->l, below, t, s);
 }
-static int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
-static int fe_eq(const fe *a, const fe *b) { return memcmp(a->l, b->l, 32) == 0; }
-static void fe_neg(fe *r, const fe *a, const field_t *F) {
+/* Fp::sub_assign: a - b, plus p if that borrowed */
+INL void fe_sub(fe *r, const fe *a, const fe *b, const field_t *F) {
+    u64 t[4], s[4];
+    const u64 borrowed = sub4(t, a->l, b->l);
+    add4(s, t, F->p);
+    sel4(r->l, borrowed, s, t);
+}
+INL int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+INL int fe_eq(const fe *a, const fe *b) { return ((a->l[0] ^ b->l[0]) | (a->l[1] ^ b->l[1]) | (a->l[2] ^ b->l[2]) | (a->l[3] ^ b->l[3])) == 0; }
+INL void fe_neg(fe *r, const fe *a, const field_t *F) {
     if (fe_is_zero(a)) { *r = *a; return; }
     sub4(r->l, F->p, a->l);
 }
-static void fe_dbl(fe *r, const fe *a, const field_t *F) { fe_add(r, a, a, F); }
+INL void fe_dbl(fe *r, const fe *a, const field_t *F) { fe_add(r, a, a, F); }
 
 /* CIOS Montgomery multiplication, the four rows written out.  Both Pasta moduli are below 2^255, so the running value stays
  * below 2 p < 2^256 and needs no fifth word: ark-ff's "no-carry" variant for moduli with a spare top bit
- * (ark-ff 0.5 montgomery_backend.rs, mul_assign: `can_use_no_carry_mul_optimization`). */
+ * (ark-ff 0.5 montgomery_backend.rs, mul_assign: `can_use_no_carry_mul_optimization`; pinned by code/Cargo.lock). */
 #define MUL_ROW(bi) do { \
         u128 c = (u128)a0 * (bi) + t0; u64 lo = (u64)c; c >>= 64; \
         u64 m = lo * inv; \
@@ -89,17 +117,18 @@ static void fe_dbl(fe *r, const fe *a, const field_t *F) { fe_add(r, a, a, F); }
         c += (u128)a3 * (bi) + t3; k += (u128)m * p3 + (u64)c; t2 = (u64)k; c >>= 64; k >>= 64; \
         t3 = (u64)c + (u64)k; \
     } while (0)
-static void fe_mul(fe *r, const fe *a, const fe *b, const field_t *F) {
+INL void fe_mul(fe *r, const fe *a, const fe *b, const field_t *F) {
     const u64 a0 = a->l[0], a1 = a->l[1], a2 = a->l[2], a3 = a->l[3];
     const u64 b0 = b->l[0], b1 = b->l[1], b2 = b->l[2], b3 = b->l[3];
     const u64 p0 = F->p[0], p1 = F->p[1], p2 = F->p[2], p3 = F->p[3], inv = F->inv;
     u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     MUL_ROW(b0); MUL_ROW(b1); MUL_ROW(b2); MUL_ROW(b3);
-    u64 t[4] = {t0, t1, t2, t3};
-    if (ge4(t, F->p)) sub4(t, t, F->p);
-    memcpy(r->l, t, 32);
+    const u64 t[4] = {t0, t1, t2, t3};
+    u64 s[4];
+    const u64 below = sub4(s, t, F->p);
+    sel4(r->l, below, t, s);
 }
-static void fe_sqr(fe *r, const fe *a, const field_t *F) { fe_mul(r, a, a, F); }
+INL void fe_sqr(fe *r, const fe *a, const field_t *F) { fe_mul(r, a, a, F); }
 static void fe_to_mont(fe *r, const fe *canon, const field_t *F) { fe_mul(r, canon, &F->r2, F); }
 static void fe_from_mont(fe *r, const fe *m, const field_t *F) { fe one = {{1, 0, 0, 0}}; fe_mul(r, m, &one, F); }
 static void fe_pow(fe *r, const fe *a, const u64 e[4], const field_t *F) {
@@ -117,29 +146,43 @@ static int fe_inv(fe *r, const fe *a, const field_t *F) {
     return 1;
 }
 
-static void field_setup(field_t *F, const u64 p[4]) {
-    memcpy(F->p, p, 32);
-    u64 x = 1; /* Newton: x = p^-1 mod 2^64 */
-    for (int i = 0; i < 6; i++) x *= 2 - p[0] * x;
-    F->inv = (u64)0 - x;
-    fe one = {{1, 0, 0, 0}};
-    fe acc = one;
+/* every constant of a field_t recomputed from p alone (Newton for -p^-1, 512 modular doublings for R and R^2) */
+static int field_selfcheck(const field_t *F) {
+    u64 x = 1;
+    for (int i = 0; i < 6; i++) x *= 2 - F->p[0] * x;
+    if (F->inv != (u64)0 - x) return 0;
+    fe acc = {{1, 0, 0, 0}};
     for (int i = 0; i < 512; i++) {
         fe_add(&acc, &acc, &acc, F);
-        if (i == 255) F->one = acc;
+        if (i == 255 && !fe_eq(&acc, &F->one)) return 0;
     }
-    F->r2 = acc;
-    u64 two[4] = {2, 0, 0, 0};
-    sub4(F->pm2, p, two);
+    if (!fe_eq(&acc, &F->r2)) return 0;
+    u64 two[4] = {2, 0, 0, 0}, pm2[4];
+    sub4(pm2, F->p, two);
+    return memcmp(pm2, F->pm2, 32) == 0;
 }
 
 static void ensure_init(void) {
     if (g_init) return;
-    static const u64 P[4] = {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0ULL, 0x4000000000000000ULL};
-    static const u64 Rr[4] = {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0ULL, 0x4000000000000000ULL};
-    field_setup(&FQ, P);
-    field_setup(&FR, Rr);
+    if (!field_selfcheck(&FQ) || !field_selfcheck(&FR)) { fprintf(stderr, "oracle: field constants do not match their moduli\n"); abort(); }
     g_init = 1;
+}
+
+/* ns per Fq Montgomery product on this host: four independent chains (the point formulas offer at least that much parallelism),
+ * so the figure is the product's throughput, which is what an MSM's cost is made of.  bench.py puts it into cpu_baseline. */
+double orc_bench_fq_mul(size_t iters, uint64_t out[4]) {
+    ensure_init();
+    fe x[4], b = FQ.r2;
+    for (int k = 0; k < 4; k++) { x[k] = FQ.one; x[k].l[0] ^= (u64)k; }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t i = 0; i < iters; i++)
+        for (int k = 0; k < 4; k++) fe_mul(&x[k], &x[k], &b, &FQ);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    fe acc = x[0];
+    for (int k = 1; k < 4; k++) fe_add(&acc, &acc, &x[k], &FQ);
+    memcpy(out, acc.l, 32);
+    return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / ((double)iters * 4.0);
 }
 
 /* ------------------------------------------------------------------ curve */
@@ -227,7 +270,7 @@ static void aff_neg(aff *r, const aff *p) { r->x = p->x; fe_neg(&r->y, &p->y, &F
 /* CurveGroup::into_affine: one field inversion per point (group.rs:19) */
 static void jac_to_aff(aff *r, const jac *p) {
     if (jac_is_inf(p)) { memset(r, 0, sizeof *r); return; }
-    fe zi, zi2, zi3;
+    fe zi = {{0, 0, 0, 0}}, zi2, zi3;
     fe_inv(&zi, &p->Z, &FQ);
     fe_sqr(&zi2, &zi, &FQ);
     fe_mul(&zi3, &zi2, &zi, &FQ);

@@ -44,6 +44,8 @@ void orc_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 void orc_fr_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 int orc_fr_inv(const uint64_t a[4], uint64_t out[4]);
 void orc_fq_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+/* ns per Fq Montgomery product on this host (four independent chains); out = a value that depends on every product */
+double orc_bench_fq_mul(size_t iters, uint64_t out[4]);
 /* jacobian -> canonical affine bytes: 32 B x LE, 32 B y LE; returns 1 if infinity */
 int orc_point_canonical(const uint64_t jac[12], uint8_t out64[64]);
 void orc_point_add(const uint64_t a[12], const uint64_t b[12], uint64_t out[12]);

@@ -12,25 +12,31 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# ORC_NATIVE=1 (bench.py's cpu_baseline leg sets it before importing this module): the library compiled with -march=native on
-# the host it runs on; falls back to the portable build (and says so in BUILD_FLAGS) if that compile is not possible
+# ORC_NATIVE=1: the library compiled with -march=native on the host it runs on; falls back to the portable build (and says so in
+# BUILD_FLAGS) if that compile is not possible.  The compiler is the Makefile's choice (the image's clang, else gcc) unless
+# select_fastest() below has picked another.
 NATIVE = os.environ.get("ORC_NATIVE") == "1"
 LIB_PATH = os.path.join(HERE, "_build", "liborc_native.so" if NATIVE else "liborc.so")
 BUILD_FLAGS = "-O3 -march=native" if NATIVE else "-O3 -march=x86-64-v2"
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+def _host() -> str:
+    try:
+        return [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0].strip()
+    except (OSError, IndexError):
+        return "unknown"
 
 
 def build(force: bool = False) -> str:
     global LIB_PATH, BUILD_FLAGS
-    src = os.path.join(HERE, "halo_cpu.c")
+    src = [os.path.join(HERE, f) for f in ("halo_cpu.c", "halo_cpu.h", "Makefile")]
     stamp = os.path.join(HERE, "_build", "native.host")
     host = ""
     if NATIVE:  # a native binary belongs to the CPU it was built on: rebuilt when the host's CPU model differs from the stamp
-        try:
-            host = [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0].strip()
-        except (OSError, IndexError):
-            host = "unknown"
+        host = _host()
         force = force or not os.path.exists(stamp) or open(stamp).read() != host
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in src):
         try:
             if NATIVE and os.path.exists(LIB_PATH):
                 os.remove(LIB_PATH)
@@ -47,35 +53,58 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _load(path):
+    l = C.CDLL(path)
+    l.orc_last_error.restype = C.c_char_p
+    l.orc_rng_u64.restype = C.c_uint64
+    l.orc_bench_fq_mul.restype = C.c_double
+    return l
+
+
 def select_fastest(log_n: int = 13):
-    """bench.py's cpu_baseline leg: build BOTH the portable (-march=x86-64-v2) and the host-native (-march=native) library,
-    time one MSM of 2^log_n points with each and keep the faster one for everything that follows -- with this image's gcc 11 the
-    native build is not always the faster one (EPYC 9575F: 0.165 against 0.186 MSM/s at 2^20).  -> {flags: seconds}"""
+    """bench.py's cpu_baseline leg: build the restatement with every compiler the host has (the image's clang, gcc) for the
+    portable instruction set and for the host's own (-march=native), time one MSM of 2^log_n points with each and keep the
+    fastest for everything that follows -- which one that is depends on compiler and CPU (gcc 11's native code was the slower
+    one on an EPYC 9575F; clang's carry chains are half as long as gcc 11's).  -> {"<compiler> <flags>": seconds}"""
     global _lib, LIB_PATH, BUILD_FLAGS, NATIVE
+    import shutil
     import time
     timings, libs = {}, {}
-    for native in (False, True):
-        NATIVE = native
-        LIB_PATH = os.path.join(HERE, "_build", "liborc_native.so" if native else "liborc.so")
-        BUILD_FLAGS = "-O3 -march=native" if native else "-O3 -march=x86-64-v2"
+    compilers = [c for c in (CLANG if os.path.exists(CLANG) else shutil.which("clang"), shutil.which("gcc")) if c]
+    for cc in compilers:
+        for march in ("x86-64-v2", "native"):
+            tag = "%s -O3 -march=%s" % (os.path.basename(cc), march)
+            out = os.path.join("_build", "liborc_%s_%s.so" % (os.path.basename(cc), march))
+            try:
+                subprocess.check_call(["make", "-C", HERE, "-s", "-B", "CC=" + cc, "MARCH=" + march, "OUT=" + out],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                l = _load(os.path.join(HERE, out))
+            except Exception:  # noqa: BLE001 -- this compiler / flag pair does not build here: the others are what there is
+                continue
+            _lib = l
+            n = 1 << log_n
+            gs, (sc, _) = urs_affine(2, n), rng_scalars(7, n)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                msm_affine(gs, sc)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            timings[tag] = best
+            libs[tag] = (l, os.path.join(HERE, out), march == "native")
+    if not timings:  # no compiler on this host: the prebuilt portable library is what there is
         _lib = None
-        try:
-            l = lib()
-        except Exception:  # noqa: BLE001 -- no compiler on this host: the prebuilt portable library is what there is
-            continue
-        n = 1 << log_n
-        gs, (sc, _) = urs_affine(2, n), rng_scalars(7, n)
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            msm_affine(gs, sc)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        timings[BUILD_FLAGS] = best
-        libs[BUILD_FLAGS] = (l, LIB_PATH, native)
+        lib()
+        return {}
     BUILD_FLAGS = min(timings, key=timings.get)
     _lib, LIB_PATH, NATIVE = libs[BUILD_FLAGS]
     return timings
+
+
+def ns_per_field_product(iters: int = 4_000_000) -> float:
+    """Throughput of the loaded library's Fq Montgomery product on this host, ns (best of three)."""
+    o = z(4)
+    return min(lib().orc_bench_fq_mul(C.c_size_t(iters), ptr(o)) for _ in range(3))
 
 
 u64p = C.POINTER(C.c_uint64)
@@ -92,9 +121,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(LIB_PATH)
-        _lib.orc_last_error.restype = C.c_char_p
-        _lib.orc_rng_u64.restype = C.c_uint64
+        _lib = _load(LIB_PATH)
     return _lib
 
 

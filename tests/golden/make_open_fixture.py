@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/open_2_19.json: pcdl::open proofs at n = 2^19 from the CPU oracle.
+"""Generates tests/golden/open_2_<lg>.json: pcdl::open proofs at n = 2^lg from the CPU oracle (lg = 19 and 20 are committed).
 
 Why: the HIP fold kernel switches to two points per lane sharing one inversion once a round folds
 m >= 2^18 points (ipa.hip ipa_fold_points), i.e. from n = 2^19 on; the oracle (double-and-add fold,
@@ -7,7 +7,13 @@ one into_affine inversion per point -- pcdl.rs:204-224, group.rs:19) needs minut
 its output is committed as a fixture instead of being recomputed in the GPU test.  The fixture is
 data: seeds, the proof blob's SHA-256 and a few of its fields for diagnosis.
 
-Run in the build container (about 6 minutes on 3 cores):  python tests/golden/make_open_fixture.py
+n = 2^20 is BASELINE config 3's size: the only size at which an open runs the tagged L/R launch over the c = 20 table
+(msm.hip MsmBatch::tagged, ipa.hip k_nofold_expand_tagged) and the c = 20 table plan.  With --acc the file also holds one
+acc::prover step (acc.rs:190-220) over two random instances (benches/acc.rs:15-29) at the same size: SHA-256 of both
+instance blobs and of the accumulator blob, plus the accumulator's fields.
+
+Run in the build container:  python tests/golden/make_open_fixture.py [lg] [--acc]
+(lg = 19: about 6 minutes on 3 cores; lg = 20 --acc: about 15 minutes on 5 cores)
 """
 import hashlib
 import json
@@ -24,8 +30,11 @@ import numpy as np
 
 import orc
 
-LG = 19
+LG = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 19
+WITH_ACC = "--acc" in sys.argv
 N = 1 << LG
+Q_SEEDS = (0x48414C4F00000041, 0x48414C4F00000042)
+ACC_SEED = 0x48414C4F00000043
 COEFF_SEED = 0x48414C4F00000003
 OPEN_SEED = 4242
 
@@ -67,10 +76,30 @@ def main():
                      "U": hexw(pf[o: o + 12]), "c": hexw(pf[o + 12: o + 16])}
         print(name, time.time() - t0, flush=True)
 
+    qs = [None, None]
+
+    def inst(k):
+        qs[k] = orc.random_instance(pp, Q_SEEDS[k], d)
+        print("instance", k, time.time() - t0, flush=True)
+
     th = [threading.Thread(target=case, args=("plain", None)), threading.Thread(target=case, args=("hiding", zw[1]))]
+    if WITH_ACC:
+        th += [threading.Thread(target=inst, args=(k,)) for k in range(2)]
     [t.start() for t in th]; [t.join() for t in th]
     out["cases"] = {k: res[k] for k in ("plain", "hiding")}
-    with open(os.path.join(HERE, "open_2_19.json"), "w") as f:
+    if WITH_ACC:
+        acc, st = orc.acc_prover(pp, ACC_SEED, d, [q for q, _ in qs])
+        orc.acc_verifier(pp, d, [q for q, _ in qs], acc)  # the oracle's own verifier and decider accept it
+        orc.acc_decider(pp, acc)
+        iw = orc.instance_words(LG)
+        out["acc"] = {"q_seeds": [format(x, "016x") for x in Q_SEEDS], "acc_seed": format(ACC_SEED, "016x"),
+                      "q_sha256": [hashlib.sha256(q.tobytes()).hexdigest() for q, _ in qs],
+                      "q_rng_state_after": [format(s_, "016x") for _, s_ in qs],
+                      "q_head": [hexw(q[:21]) for q, _ in qs],  # C, d, z, v of each instance
+                      "acc_sha256": hashlib.sha256(acc.tobytes()).hexdigest(), "acc_rng_state_after": format(st, "016x"),
+                      "acc_head": hexw(acc[:21]), "acc_tail": hexw(acc[iw:])}  # instance head; (C_bar', alpha... ) words behind it
+        print("acc", time.time() - t0, flush=True)
+    with open(os.path.join(HERE, "open_2_%d.json" % LG), "w") as f:
         json.dump(out, f, indent=1)
     print("done", time.time() - t0)
 

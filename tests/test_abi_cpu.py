@@ -20,8 +20,8 @@ def hal():
     return h
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "halo_accumulation.h")).read()
+def header_symbols(name="halo_accumulation.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(halo_[a-z0-9_]+)\s*\(", text)))
 
@@ -34,6 +34,35 @@ def test_library_exports_every_declared_symbol(hal):
         assert hasattr(lib, s), "missing export: " + s
     # and the Python binding covers the same set
     assert sorted(hal._lib.declared_symbols()) == syms
+
+
+def test_development_library_is_separate(hal):
+    """the shipped library exports no test hook, bench hook or fault injector and reads no injector from the
+    environment; they live in libhalo_hip_dev.so (include/halo_accumulation_dev.h), which links against the product library.
+    The environment is read in ONE translation unit (csrc/tuning.hip)."""
+    import subprocess
+    prod = subprocess.check_output(["nm", "-D", "--defined-only", hal._lib.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (halo_[a-z0-9_]+)$", prod, flags=re.M)))
+    assert exported == header_symbols(), "the product library exports exactly what its header declares"
+    assert not [s for s in exported if s.startswith(("halo_test", "halo_bench", "halo_dev_"))]
+    dev_syms = header_symbols("halo_accumulation_dev.h")
+    dev = subprocess.check_output(["nm", "-D", "--defined-only", hal._lib.DEV_LIB_PATH], text=True)
+    dev_exported = sorted(set(re.findall(r" T (halo_[a-z0-9_]+)$", dev, flags=re.M)))
+    assert dev_exported == dev_syms == sorted(hal._lib.declared_dev_symbols())
+    assert "halo_dev_hook" in dev_syms and "halo_test_field_op" in dev_syms
+    needed = subprocess.check_output(["readelf", "-d", hal._lib.DEV_LIB_PATH], text=True)
+    assert "libhalo_hip.so" in needed, "the development library links against the product library (one state per process)"
+    # no injector name in the product binary, no getenv outside tuning.hip
+    blob = open(hal._lib.LIB_PATH, "rb").read()
+    assert b"HALO_TEST_" not in blob
+    csrc = os.path.join(ROOT, "halo-accumulation_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".cpp")) and f != "tuning.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f + ": the environment is read in tuning.hip only"
+    # the hooks work through the development library and are off by default (host-only call: no GPU needed)
+    lib = hal.load()
+    assert lib.halo_dev_hook(b"table_fail", 1) == 0 and lib.halo_dev_hook(b"reset", 0) == 0
+    assert lib.halo_dev_hook(b"no_such_hook", 1) == hal._lib.HALO_E_ARG
 
 
 def test_public_points_match_consts_rs(hal, kat):

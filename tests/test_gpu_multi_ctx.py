@@ -97,7 +97,7 @@ def test_multi_ctx_batched_launches(hal, P, batch, monkeypatch):
     try:
         for forced in (False, True):
             if forced:
-                monkeypatch.setenv("HALO_TEST_FORCE_PEER_COPY", "1")
+                hal.dev_hook("force_peer_copy", 1)
             for slot in (0, 1):
                 c.msm_dev_batch_begin(slot, [d.data_ptr() for d in ds], n)
             for slot in (0, 1):
@@ -112,7 +112,7 @@ def test_multi_ctx_batched_launches(hal, P, batch, monkeypatch):
 
 def test_multi_ctx_peer_copy_path(hal, monkeypatch):
     """Device-resident scalars on a GPU other than a shard's are copied peer-to-peer into the shard's slot buffer in front of
-    its launches.  One GPU here, so the copy path is forced (HALO_TEST_FORCE_PEER_COPY): hipMemcpyPeerAsync between a
+    its launches.  One GPU here, so the copy path is forced (the development library's force_peer_copy hook): hipMemcpyPeerAsync between a
     device and itself is a device-to-device copy; buffers, ordering and offsets are the real ones."""
     import torch
     n = 1 << 18
@@ -123,7 +123,7 @@ def test_multi_ctx_peer_copy_path(hal, monkeypatch):
         torch.cuda.synchronize()
         want = c.msm_dev(d.data_ptr(), n)
         want_off = c.msm_dev(d.data_ptr() + 32 * 1000, n - 5000, off=3000)
-        monkeypatch.setenv("HALO_TEST_FORCE_PEER_COPY", "1")
+        hal.dev_hook("force_peer_copy", 1)
         for _ in range(2):
             assert c.msm_dev(d.data_ptr(), n).tolist() == want.tolist()
             assert c.msm_dev(d.data_ptr() + 32 * 1000, n - 5000, off=3000).tolist() == want_off.tolist()

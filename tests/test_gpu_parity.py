@@ -441,14 +441,14 @@ def test_table_memory_failure_and_release(hal, monkeypatch):
         assert good.msm(sc).tolist() == want.tolist()
     finally:
         good.close()
-    monkeypatch.setenv("HALO_TEST_TABLE_FAIL", "1")   # the allocation of the table fails
+    hal.dev_hook("table_fail", 1)   # the allocation of the table fails (development library's hook)
     bad = hal.Context(urs_n=n)
     try:
         for _ in range(3):
             assert bad.msm(sc).tolist() == want.tolist()
         assert bad.info(0) == 0 and bad.info(6) == 4
         # no latch: with the memory back, the table is built at the attempt after the back-off (64 eligible MSMs)
-        monkeypatch.delenv("HALO_TEST_TABLE_FAIL")
+        hal.dev_hook("table_fail", 0)
         built_after = None
         for k in range(70):
             assert bad.msm(sc).tolist() == want.tolist()

@@ -508,6 +508,97 @@ def test_open_2_19_matches_oracle_fixture(hal):
         c.close()
 
 
+def _open_fixture_cases(hal, fx, c, coeffs, zw, label):
+    """one context configuration against every case of an open fixture (tests/golden/open_2_<lg>.json)"""
+    import hashlib
+    from halo_accumulation_amd import pcdl
+    lg = fx["lg_n"]
+    d = (1 << lg) - 1
+    words = lambda h: np.array([int(x, 16) for x in h], dtype=np.uint64)
+    for name in ("plain", "hiding"):
+        case = fx["cases"][name]
+        w = zw[1] if case["hiding"] else None
+        C = pcdl.commit(c, coeffs, d, w)
+        assert C.tolist() == words(case["C"]).tolist(), label
+        rng = [fx["open_seed"]]
+        pi = pcdl.open(c, rng, coeffs, C, d, zw[0], w)
+        o = 2 + 24 * lg
+        assert pi[2:14].tolist() == words(case["L0"]).tolist(), label + ": L of the first round"
+        assert pi[2 + 12 * lg: 14 + 12 * lg].tolist() == words(case["R0"]).tolist(), label + ": R of the first round"
+        assert pi[14:26].tolist() == words(case["L1"]).tolist(), label + ": L of the second round"
+        assert pi[2 + 12 * (lg - 1): 2 + 12 * lg].tolist() == words(case["L_last"]).tolist(), label
+        assert pi[o: o + 12].tolist() == words(case["U"]).tolist() and pi[o + 12: o + 16].tolist() == words(case["c"]).tolist(), label
+        assert hashlib.sha256(pi.tobytes()).hexdigest() == case["proof_sha256"], label + ": the whole proof"
+        assert rng[0] == int(case["rng_state_after"], 16)
+        v = c.poly_eval(coeffs, zw[0])
+        assert v.tolist() == words(case["v"]).tolist()
+        pcdl.check_proof(c, C, d, zw[0], v, pi)
+
+
+def test_open_2_20_matches_oracle_fixture(hal):
+    """BASELINE config 3 at its own size against the ORACLE's proof (tests/golden/open_2_20.json: orc_pcdl_open, 4.5 minutes of CPU
+    per proof in the build container, tests/golden/make_open_fixture.py 20 --acc) -- pcdl.rs:120-242.  n = 2^20 is the only
+    size at which an open takes the tagged L/R launch over the c = 20 table (msm.hip MsmBatch::tagged, ipa.hip
+    k_nofold_expand_tagged), the c = 20 table plan inside an open and (from the K-th open on) the comb-table fold.  Compared,
+    hiding and not: (a) the default configuration as a fresh context runs it, (b) with the fold table forced in, (c) with
+    neither table (halo_set_table_mode(0), halo_set_fold_table(0): general pipeline, Straus fold)."""
+    import json, os
+    with open(os.path.join(ROOT, "tests", "golden", "open_2_20.json")) as f:
+        fx = json.load(f)
+    assert fx["lg_n"] == 20
+    n = 1 << 20
+    c = hal._lib.Context(urs_n=n)
+    try:
+        coeffs, s = orc.rng_scalars(fx["coeff_seed"], fx["deg"] + 1)
+        zw, _ = orc.rng_scalars(s, 2)
+        _open_fixture_cases(hal, fx, c, coeffs, zw, "default configuration")
+        assert c.info(0) > 0, "the c = 20 table is in place: the opens above took the tagged launch"
+        c.set_fold_table(1)
+        _open_fixture_cases(hal, fx, c, coeffs, zw, "fold table forced")
+        assert c.info(1) > 0, "the fold table was built"
+        c.set_fold_table(0)
+        c.set_table_mode(0)
+        assert c.info(0) == 0 and c.info(1) == 0
+        _open_fixture_cases(hal, fx, c, coeffs, zw, "no tables")
+    finally:
+        c.close()
+
+
+def test_acc_prover_2_20_matches_oracle_fixture(hal):
+    """One acc::prover step (acc.rs:190-220) over two random instances (benches/acc.rs:15-29) at n = 2^20 against the oracle's
+    accumulator (tests/golden/open_2_20.json "acc": ~13 minutes of CPU): both instances and the accumulator blob for blob
+    (SHA-256), RNG states included; verifier and decider accept it."""
+    import hashlib, json, os
+    from halo_accumulation_amd import acc as A
+    with open(os.path.join(ROOT, "tests", "golden", "open_2_20.json")) as f:
+        fx = json.load(f)
+    a = fx["acc"]
+    n = 1 << fx["lg_n"]
+    d = n - 1
+    words = lambda h: np.array([int(x, 16) for x in h], dtype=np.uint64)
+    c = hal._lib.Context(urs_n=n)
+    try:
+        qs = []
+        for k in range(2):
+            rng = [int(a["q_seeds"][k], 16)]
+            q = A.random_instance(c, rng, d)
+            assert q[:21].tolist() == words(a["q_head"][k]).tolist(), "C, d, z, v of instance %d" % k
+            assert hashlib.sha256(q.tobytes()).hexdigest() == a["q_sha256"][k], "instance %d" % k
+            assert rng[0] == int(a["q_rng_state_after"][k], 16)
+            qs.append(q)
+        rng = [int(a["acc_seed"], 16)]
+        acc = A.prover(c, rng, d, qs)
+        iw = 21 + 2 + 24 * fx["lg_n"] + 32
+        assert acc[:21].tolist() == words(a["acc_head"]).tolist(), "C_bar, d, z, v of the accumulator"
+        assert acc[iw:].tolist() == words(a["acc_tail"]).tolist(), "h0, U0, w of the accumulator"
+        assert hashlib.sha256(acc.tobytes()).hexdigest() == a["acc_sha256"]
+        assert rng[0] == int(a["acc_rng_state_after"], 16)
+        A.verifier(c, d, qs, acc)
+        A.decider(c, acc)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("lg", [6, 9, 12, 15])
 def test_open_with_fold_table_matches_oracle(hal, lg):
     """The first fold of an open from the comb table over the context's key (foldtab.hip: 64 entries added up per scalar, no
@@ -675,14 +766,14 @@ def test_fold_table_memory_failure_falls_back(hal, monkeypatch):
         C = pcdl.commit(c, coeffs, d)
         c.set_fold_table(0)
         want = pcdl.open(c, [9], coeffs, C, d, zw[0])
-        monkeypatch.setenv("HALO_TEST_TABLE_FAIL", "1")
+        hal._lib.dev_hook("table_fail", 1)
         c.set_fold_table(1)
         for _ in range(2):
             assert pcdl.open(c, [9], coeffs, C, d, zw[0]).tolist() == want.tolist()
         assert c.info(1) == 0 and c.info(5) == 4, "allocation failed: status 4, tried again later"
         # no latch.  The memory is back (the hook is gone): the table is tried again after the back-off -- eight more
         # opens -- without any call from the caller, and nothing it held during the failed attempts stayed on the budget's books
-        monkeypatch.delenv("HALO_TEST_TABLE_FAIL")
+        hal._lib.dev_hook("table_fail", 0)
         used = c.info(4)
         built_after = None
         for k in range(12):
@@ -807,7 +898,7 @@ def test_sharded_open_two_and_four_ranks_on_one_gpu(world, n):
 
 
 def _sharded_fail_worker(rank, world, port, n, q):
-    """Rank 1 is made to fail locally at several points of a sharded open / check (HALO_TEST_SHARD_FAIL, and a Python
+    """Rank 1 is made to fail locally at several points of a sharded open / check (the development library's shard_fail hooks, and a Python
     exception in the by-rounds driver): EVERY rank must come back with an error from the same collective -- nobody hangs."""
     import os, sys
     for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -844,21 +935,21 @@ def _sharded_fail_worker(rank, world, port, n, q):
     lg_l = (n // world).bit_length() - 1
     outcomes = []
     for step, hiding in ((0, False), (0, True), (1, False), (lg_l // 2, False), (lg_l, True), (lg_l + 1, False)):
-        os.environ["HALO_TEST_SHARD_FAIL"] = "1:%d" % step  # offset 1 fails before collective `step`
+        h._lib.dev_hook("shard_fail_rank", 1); h._lib.dev_hook("shard_fail_at", step)  # offset 1 fails before collective `step`
         calls[0] = 0
         try:
             so.open(local, C, z[0], w=wz[0] if hiding else None, rng=[7], deg=n - 1)
             outcomes.append(("open", step, "returned", calls[0]))
         except h._lib.HaloError as e:
             outcomes.append(("open", step, "HaloError", calls[0], "injected" in str(e), "rank 1" in str(e)))
-    os.environ["HALO_TEST_SHARD_FAIL"] = "1:check"
+    h._lib.dev_hook("shard_fail_at", -2)  # ... in the check
     calls[0] = 0
     try:
         so.check(C, n - 1, z[0], v, proof)
         outcomes.append(("check", "returned"))
     except h._lib.HaloError as e:
         outcomes.append(("check", "HaloError", calls[0], "injected" in str(e), "rank 1" in str(e)))
-    del os.environ["HALO_TEST_SHARD_FAIL"]
+    h._lib.dev_hook("reset", 0)
     # the same rule in the by-rounds Python driver: rank 1's third round raises
     if rank == 1:
         orig, seen = h._lib.Ipa.round_lr_partial, [0]
