@@ -469,29 +469,39 @@ int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out[12]) { return halo_msm_de
 // bit (points written by the library are normalised).  Not taken: multi-device contexts (each shard copies its own block over
 // its own link already), contexts without the c = 20 table (the first MSM of a context builds it), any slot busy.
 static int host_pieces_wanted(const halo_ctx *ctx, size_t n) {
-    const int P = halo::tuning().host_pieces;
+    const int P = halo::tuning().host_pieces;  // (= the number of entries of tuning().host_split)
     if (P < 2 || !ctx->shards.empty() || !ctx->d_table || ctx->tbl.c != 20 || ctx->table_mode == 0 || ctx->window_bits != 0) return 1;
-    if (n < ((size_t)1 << 19) || n % (4 * (size_t)P) != 0) return 1;
+    if (n < ((size_t)1 << 19) || n % 64 != 0) return 1;
     for (int k = 0; k < P; ++k)
         if (ctx->wss[k].in_flight || ctx->wss[k].lent_from >= 0) return 1;
     return P;
 }
 static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uint64_t *scalars, int mont, host::Point *out) {
-    const size_t len = n / (size_t)P;
+    // stretch k takes host_split[k] sixteenths of the points (n is a multiple of 64: every length a multiple of 4), the last one the rest
+    size_t lens[HALO_SLOTS], offs[HALO_SLOTS];
+    {
+        size_t at = 0;
+        for (int k = 0; k < P; ++k) {
+            lens[k] = k == P - 1 ? n - at : n / 64 * (size_t)tuning().host_split[k];
+            offs[k] = at;
+            at += lens[k];
+        }
+    }
     int rc = HALO_OK, started = 0;
     for (int k = 0; k < P && !rc; ++k) {
+        const size_t len = lens[k];
         if (!ctx->d_slot_scalars[k]) {
             alloc_epoch_bump(ctx);
             hipError_t e = hipMalloc(&ctx->d_slot_scalars[k], (ctx->n < 64 ? 64 : ctx->n) * 32);
             if (e != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
         }
-        hipError_t e = hipMemcpyAsync(ctx->d_slot_scalars[k], scalars + 4 * len * (size_t)k, len * 32, hipMemcpyHostToDevice, ctx->streams[k]);
+        hipError_t e = hipMemcpyAsync(ctx->d_slot_scalars[k], scalars + 4 * offs[k], len * 32, hipMemcpyHostToDevice, ctx->streams[k]);
         if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync"); break; }
         MsmBatch one;
         one.count = 1;
         one.scalars[0] = ctx->d_slot_scalars[k];
         one.sub = true;
-        rc = msm_enqueue_batch(ctx, k, ctx->d_bases + 32 * (off + len * (size_t)k), one, mont != 0, len);
+        rc = msm_enqueue_batch(ctx, k, ctx->d_bases + 32 * (off + offs[k]), one, mont != 0, len);
         if (!rc) started = k + 1;
     }
     host::Point acc = host::Point::infinity();

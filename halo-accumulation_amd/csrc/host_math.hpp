@@ -6,7 +6,9 @@
 //
 // This is product code (linked into libhalo_hip.so); it shares nothing with oracle/.
 #pragma once
+#if defined(__x86_64__)
 #include <x86intrin.h>
+#endif
 #include <array>
 #include <cstdint>
 #include <cstdlib>
@@ -20,6 +22,22 @@ inline bool g_inv_fermat = false;  // set from tuning() when a context is create
 
 using u64 = uint64_t;
 using u128 = unsigned __int128;
+
+// add / subtract with carry, and the spin-wait hint: the x86 intrinsics where the host is one (adc / sbb chains without a
+// branch), plain 128-bit arithmetic anywhere else -- the library builds on any 64-bit host an MI355X can sit in
+#if defined(__x86_64__)
+inline unsigned char addc64(unsigned char c, u64 a, u64 b, unsigned long long *out) { return _addcarry_u64(c, a, b, out); }
+inline unsigned char subb64(unsigned char b, u64 a, u64 c, unsigned long long *out) { return _subborrow_u64(b, a, c, out); }
+inline void cpu_relax() { __builtin_ia32_pause(); }
+#else
+inline unsigned char addc64(unsigned char c, u64 a, u64 b, unsigned long long *out) { u128 s = (u128)a + b + c; *out = (u64)s; return (unsigned char)(s >> 64); }
+inline unsigned char subb64(unsigned char b, u64 a, u64 c, unsigned long long *out) { u128 d = (u128)a - c - b; *out = (u64)d; return (unsigned char)((d >> 64) & 1); }
+inline void cpu_relax() {
+#if defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+#endif
 
 struct FqP {
     static constexpr u64 M[4] = {0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0ULL, 0x4000000000000000ULL};
@@ -199,28 +217,28 @@ struct Fp {
     // whether M has to come off again is the borrow of the trial subtraction.
     Fp operator+(const Fp &o) const {
         unsigned long long s0, s1, s2, s3, d0, d1, d2, d3;
-        unsigned char c = _addcarry_u64(0, l[0], o.l[0], &s0);
-        c = _addcarry_u64(c, l[1], o.l[1], &s1);
-        c = _addcarry_u64(c, l[2], o.l[2], &s2);
-        (void)_addcarry_u64(c, l[3], o.l[3], &s3);
-        unsigned char b = _subborrow_u64(0, s0, P::M[0], &d0);
-        b = _subborrow_u64(b, s1, P::M[1], &d1);
-        b = _subborrow_u64(b, s2, P::M[2], &d2);
-        b = _subborrow_u64(b, s3, P::M[3], &d3);
+        unsigned char c = addc64(0, l[0], o.l[0], &s0);
+        c = addc64(c, l[1], o.l[1], &s1);
+        c = addc64(c, l[2], o.l[2], &s2);
+        (void)addc64(c, l[3], o.l[3], &s3);
+        unsigned char b = subb64(0, s0, P::M[0], &d0);
+        b = subb64(b, s1, P::M[1], &d1);
+        b = subb64(b, s2, P::M[2], &d2);
+        b = subb64(b, s3, P::M[3], &d3);
         const u64 keep = (u64)0 - (u64)b;  // all ones: the sum was below M
         return Fp{{(s0 & keep) | (d0 & ~keep), (s1 & keep) | (d1 & ~keep), (s2 & keep) | (d2 & ~keep), (s3 & keep) | (d3 & ~keep)}};
     }
     Fp operator-(const Fp &o) const {
         unsigned long long d0, d1, d2, d3, r0, r1, r2, r3;
-        unsigned char b = _subborrow_u64(0, l[0], o.l[0], &d0);
-        b = _subborrow_u64(b, l[1], o.l[1], &d1);
-        b = _subborrow_u64(b, l[2], o.l[2], &d2);
-        b = _subborrow_u64(b, l[3], o.l[3], &d3);
+        unsigned char b = subb64(0, l[0], o.l[0], &d0);
+        b = subb64(b, l[1], o.l[1], &d1);
+        b = subb64(b, l[2], o.l[2], &d2);
+        b = subb64(b, l[3], o.l[3], &d3);
         const u64 back = (u64)0 - (u64)b;  // all ones: the difference went below zero, M goes back on
-        unsigned char c = _addcarry_u64(0, d0, P::M[0] & back, &r0);
-        c = _addcarry_u64(c, d1, P::M[1] & back, &r1);
-        c = _addcarry_u64(c, d2, P::M[2] & back, &r2);
-        (void)_addcarry_u64(c, d3, P::M[3] & back, &r3);
+        unsigned char c = addc64(0, d0, P::M[0] & back, &r0);
+        c = addc64(c, d1, P::M[1] & back, &r1);
+        c = addc64(c, d2, P::M[2] & back, &r2);
+        (void)addc64(c, d3, P::M[3] & back, &r3);
         return Fp{{r0, r1, r2, r3}};
     }
     Fp operator-() const {
@@ -260,10 +278,10 @@ struct Fp {
         }
         // t < 2M: M comes off once if t >= M -- t4 set, or no borrow from the trial subtraction (branch-free, like operator+)
         unsigned long long d0, d1, d2, d3;
-        unsigned char b = _subborrow_u64(0, t0, P::M[0], &d0);
-        b = _subborrow_u64(b, t1, P::M[1], &d1);
-        b = _subborrow_u64(b, t2, P::M[2], &d2);
-        b = _subborrow_u64(b, t3, P::M[3], &d3);
+        unsigned char b = subb64(0, t0, P::M[0], &d0);
+        b = subb64(b, t1, P::M[1], &d1);
+        b = subb64(b, t2, P::M[2], &d2);
+        b = subb64(b, t3, P::M[3], &d3);
         const u64 keep = ((u64)0 - (u64)b) & ((u64)0 - (u64)(t4 == 0));  // all ones: t was below M
         return Fp{{(t0 & keep) | (d0 & ~keep), (t1 & keep) | (d1 & ~keep), (t2 & keep) | (d2 & ~keep), (t3 & keep) | (d3 & ~keep)}};
     }

@@ -1456,8 +1456,9 @@ static int workspace_alloc_buffers(MsmWorkspace &ws, const WorkspaceNeed &need) 
     HALO_HIP(hipMalloc(&ws.d_order, ws.cap_tasks * 16));  // uint4 per task (k_msm_task_order)
     HALO_HIP(hipMalloc(&ws.d_seg, ws.cap_windows * 64 * 2 * XYZZ_WORDS * 4));
     HALO_HIP(hipMalloc(&ws.d_winsum, ws.cap_windows * 12 * 8));
-    HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8));
-    HALO_HIP(hipHostMalloc(&ws.h_done, 64));
+    // (the host reads both while the kernel that writes them is still running: fine-grained coherent, said explicitly)
+    HALO_HIP(hipHostMalloc(&ws.h_winsum, ws.cap_windows * 12 * 8, hipHostMallocCoherent));
+    HALO_HIP(hipHostMalloc(&ws.h_done, 64, hipHostMallocCoherent));
     *ws.h_done = 0;
     ws.done_expect = 0;
     if (debug_trace())  // address ranges, so that a faulting address can be mapped to a buffer
@@ -1649,7 +1650,16 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
     // enqueue with this key would.  The GPU memory fault of round 1 ("graph REPLAY ... n=262144") was a kernel with
     // SCRATCH inside a replayed graph (k_msm_reduce1: 256 VGPRs, 12 B/lane of spill) after the queue's scratch had been
     // re-assigned -- not a stale pointer: csrc/check_resources.py now fails the build if any kernel uses scratch.
+    // (msm_wait returns when the last kernel has PUBLISHED, which is before the graph's last node has retired: the stream is
+    // drained before one of its executable graphs is destroyed -- rare paths, both of them)
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(ctx->streams[slot]);
+        if (partner >= 0) (void)hipStreamSynchronize(ctx->streams[partner]);
+    };
     if (ws.graph_epoch != ctx->alloc_epoch) {
+        bool any = false;
+        for (auto &g : ws.graphs) any = any || g.exec;
+        if (any) drain();
         for (auto &g : ws.graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
             g = MsmWorkspace::CachedGraph();
@@ -1695,7 +1705,7 @@ int msm_enqueue_batch(halo_ctx *ctx, int slot, const uint32_t *d_bases, const Ms
         for (int k = 0; k < cache_n; ++k)
             if (!ws.graphs[k].exec) { victim = &ws.graphs[k]; break; }
             else if (ws.graphs[k].used < victim->used) victim = &ws.graphs[k];
-        if (victim->exec) { (void)hipGraphExecDestroy(victim->exec); *victim = MsmWorkspace::CachedGraph(); }
+        if (victim->exec) { drain(); (void)hipGraphExecDestroy(victim->exec); *victim = MsmWorkspace::CachedGraph(); }
         e = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { victim->exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
@@ -2133,10 +2143,17 @@ int msm_wait(halo_ctx *ctx, int slot, int count) {
     if (ws.plan.publishers > 0) {
         // the last kernel's blocks count themselves in as they hand over their sums (smsm.hip publish()): poll the pinned counter
         // instead of waiting for the stream -- and look at the stream now and then, in case a launch has died
+        // Waiting costs a core only briefly: the first tuning().spin_us microseconds (50) poll with the spin-wait hint -- the late
+        // rounds of an open end within that --, then every poll is followed by sched_yield() (free when nobody else wants the
+        // core, and a host running many provers shares it), and a launch that outlasts 2 ms (n >= 2^21, a shard's stretch) sleeps
+        // 50 us between polls.
         volatile uint32_t *f = ws.h_done;
+        const auto t_begin = std::chrono::steady_clock::now();
+        const long spin_us = tuning().spin_us;
+        int phase = 0;  // 0 spin, 1 yield, 2 sleep
         for (uint32_t spins = 1;; ++spins) {
             if ((int32_t)(*f - ws.done_expect) >= 0) break;
-            if ((spins & 0x3fffu) == 0) {
+            if ((spins & (phase == 0 ? 0x3fffu : 0xffu)) == 0 || phase == 2) {
                 hipError_t e = hipStreamQuery(ctx->streams[slot]);
                 if (e == hipSuccess) {
                     if ((int32_t)(*f - ws.done_expect) >= 0) break;
@@ -2146,7 +2163,17 @@ int msm_wait(halo_ctx *ctx, int slot, int count) {
                 }
                 if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
             }
-            __builtin_ia32_pause();
+            if (phase == 0) {
+                host::cpu_relax();
+                if ((spins & 0x3fu) == 0 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count() >= spin_us) phase = 1;
+            } else if (phase == 1) {
+                std::this_thread::yield();
+                if ((spins & 0x3fu) == 0 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count() >= 2000) phase = 2;
+            } else {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (ctx->prof.on) HALO_HIP(hipStreamSynchronize(ctx->streams[slot]));

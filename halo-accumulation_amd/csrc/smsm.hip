@@ -551,7 +551,9 @@ int smsm_enqueue(halo_ctx *ctx, MsmWorkspace &ws, const uint32_t *d_bases, uint3
     int logL = 0, live_seg = 1;
     while ((1u << logL) < L) logL++;
     while ((uint32_t)live_seg < nseg) live_seg <<= 1;
-    const bool fused = tuning().smsm_fused;
+    // (the fused form's per-window tickets are done[w] = d_meta[64 + w]: d_meta has 256 words, all zeroed by the recode, and word
+    // 255 is the publish ticket -- more than 191 windows keep the two-launch form)
+    const bool fused = tuning().smsm_fused && Wt <= 191;
     // (one thread per window writes its sum: straight to the slot's pinned buffer when the launch publishes, see publish())
     uint64_t *out = ctx->sink_done ? ws.h_winsum : ws.d_winsum;
     if (fused || nseg == 1) {

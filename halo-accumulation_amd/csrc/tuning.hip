@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace halo {
 namespace {
@@ -23,9 +24,20 @@ Tuning read_env() {
     if (const char *e = getenv("HALO_MEMORY_BUDGET")) { t.memory_budget_set = true; t.memory_budget = parse_bytes(e); }
     t.graphs = env_int("HALO_GRAPHS", -1);
     t.fold_async = env_int("HALO_FOLD_ASYNC", -2);
-    t.host_pieces = env_int("HALO_HOST_PIECES", t.host_pieces);
-    if (t.host_pieces < 1) t.host_pieces = 1;
-    if (t.host_pieces > 4) t.host_pieces = 4;
+    if (const char *e = getenv("HALO_HOST_SPLIT")) {
+        int v[4] = {0, 0, 0, 0}, k = 0, sum = 0;
+        for (const char *q = e; *q && k < 4; ++k) {
+            v[k] = atoi(q);
+            sum += v[k];
+            const char *comma = strchr(q, ',');
+            if (!comma) { ++k; break; }
+            q = comma + 1;
+        }
+        bool ok = k >= 1 && sum == 16;
+        for (int i = 0; i < k; ++i) ok = ok && v[i] >= 1;
+        if (ok) { t.host_pieces = k; for (int i = 0; i < 4; ++i) t.host_split[i] = v[i]; }
+        else fprintf(stderr, "[halo] HALO_HOST_SPLIT=%s ignored: 1 to 4 positive numbers of sixteenths that add up to 16\n", e);
+    }
     t.fold_table_after = env_int("HALO_FOLD_TABLE_AFTER", t.fold_table_after);
     t.plan = getenv("HALO_PLAN");
     t.dots_first = env_int("HALO_DOTS_FIRST", -1);

@@ -1,6 +1,6 @@
 """halo_msm with the scalars in PAGEABLE host memory (what integration/ffi.rs point_dot_affine does): latency of one call at
-n = 2^lg, median of K, result compared with halo_msm_dev every time.  HALO_HOST_PIECES=1..4 (csrc/tuning.hpp) sets the number
-of stretches whose copies run under the other stretches' kernels; 1 = one copy in front of one launch sequence.
+n = 2^lg, median of K, result compared with halo_msm_dev every time.  HALO_HOST_SPLIT="4,12" (csrc/tuning.hpp): the
+stretches, in sixteenths of the points, whose copies run under the other stretches' kernels; "16" = one copy, one launch sequence.
 Usage: host_msm.py LG [K=30]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +25,6 @@ ts2 = []
 for _ in range(K):
     t0 = time.perf_counter(); r = ctx.msm_dev(d.data_ptr(), n); ts2.append(time.perf_counter() - t0)
 med = lambda v: sorted(v)[len(v) // 2]
-print("lg=%d HALO_HOST_PIECES=%s halo_msm (pageable host scalars) %.3f ms (min %.3f)   halo_msm_dev %.3f ms" % (
-    lg, os.environ.get("HALO_HOST_PIECES", "default"), med(ts) * 1e3, min(ts) * 1e3, med(ts2) * 1e3))
+print("lg=%d HALO_HOST_SPLIT=%s halo_msm (pageable host scalars) %.3f ms (min %.3f)   halo_msm_dev %.3f ms" % (
+    lg, os.environ.get("HALO_HOST_SPLIT", "default"), med(ts) * 1e3, min(ts) * 1e3, med(ts2) * 1e3))
 ctx.close()
