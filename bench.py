@@ -573,13 +573,22 @@ def main():
             al2 = np.ascontiguousarray(co[100:102])
             h02 = np.ascontiguousarray(co[200:202])
             acc1 = ctx.h_accumulate(h02, xis2, al2)
-            hts2 = []
+            acc2 = np.zeros_like(acc1)
+            hts2, hts3 = [], []
             for _ in range(5):
                 t0 = time.perf_counter()
-                acc2 = ctx.h_accumulate(h02, xis2, al2)
+                ctx.h_accumulate(h02, xis2, al2, out=acc2)
                 hts2.append(time.perf_counter() - t0)
-            assert acc1.tolist() == acc2.tolist()
+                t0 = time.perf_counter()
+                acc3 = ctx.h_accumulate(h02, xis2, al2)
+                hts3.append(time.perf_counter() - t0)
+                same3 = bool((acc3 == acc1).all())
+                del acc3
+            assert bool((acc1 == acc2).all()) and same3
             dropin["h_accumulate_two_instances_ms"] = median(hts2) * 1e3
+            dropin["h_accumulate_two_instances_fresh_output_ms"] = median(hts3) * 1e3
+            dropin["h_accumulate_note"] = "32 MiB of coefficients come back to pageable host memory: into a buffer the caller reuses / into a freshly " \
+                                          "allocated one (its pages are faulted in and pinned during the copy: the operating system's time, not the GPU's)"
             ts_b, _ = timed(one, args.open_steps)  # second set, after the host-path runs
             pooled = sorted(ts_a + ts_b)
             odt = median(pooled)  # ONE median over both sets of samples (not the better of two medians)
@@ -925,7 +934,17 @@ def main():
         # (seed ...03); a rank's coefficients c[r::N] are handed over in host memory at every open.
         from halo_accumulation_amd.sharded import ShardedOpen, make_allgather
         ag = make_allgather(coll_dev)
-        so = ShardedOpen(h._lib, rank, world, ag, device=gpu, always_collective=force_dist)
+        # the collectives of the sharded open / check: libhalo_rccl.so's halo_allgather_rccl when it is built and the backend is
+        # RCCL -- the C function pointer goes straight into halo_pcdl_open_sharded, no Python (and no torch) in the collective path,
+        # the same symbol a Rust host links; torch.distributed only carries the communicator's 128-byte id to the ranks.
+        # HALO_BENCH_NATIVE_GATHER=0 keeps the torch.distributed callback.
+        native_gather = None
+        from halo_accumulation_amd import rccl as hrccl
+        if backend == "nccl" and hrccl.available() and os.environ.get("HALO_BENCH_NATIVE_GATHER", "1") != "0":
+            box = [hrccl.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            native_gather = hrccl.RcclGather(box[0], rank, world, device=gpu)
+        so = ShardedOpen(h._lib, rank, world, native_gather if native_gather is not None else ag, device=gpu, always_collective=force_dist)
         sctx = so.load_key(n)
         sctx.set_fold_table(1)  # the comb table of the first fold over this rank's shard, built at the first (warm-up) open
         d_co = torch.empty((n + 2) * 4, dtype=torch.int64, device=dev)
@@ -961,11 +980,15 @@ def main():
             result["pcdl_open_check" if world > 1 else "pcdl_open_check_collective_path"] = {
                                          "value": 1.0 / odt, "unit": "open+check/s", "ms": odt * 1e3, "n": n, "hiding": False, "ranks": world,
                                          "samples_ms": [round(x * 1e3, 3) for x in ts], "proof_equals_single_gpu": same,
+                                         "collectives": ("libhalo_rccl.so halo_allgather_rccl (native: ncclAllGather on the library's own communicator), %d calls"
+                                                         % native_gather.calls) if native_gather is not None else "torch.distributed all_gather_into_tensor through a Python callback",
                                          "note": "sharded.ShardedOpen: cyclic shards of G, c, z-powers; per round one all-gather of 256 B per "
                                                  "rank; check = succinct check on every rank + sharded commitment to h; max over ranks "
                                                  "per repetition, median reported; coefficients handed over in host memory"}
             assert same, "sharded open differs from the single-GPU open"
         so.ctx.close()
+        if native_gather is not None:
+            native_gather.close()
     if world > 1 and rank == 0:
         # cross-check of the sharded results: the same MSMs, unsharded, on this rank's GPU alone
         full = ctx if window_mode else h._lib.Context(urs_n=n, first_index=2, device=gpu)

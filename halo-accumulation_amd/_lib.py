@@ -398,10 +398,13 @@ class Context:
         check(self.lib.halo_h_eval_batch(self.h, ptr(xis), m, lg1 - 1, ptr(np.ascontiguousarray(z, dtype=np.uint64)), ptr(out)))
         return out
 
-    def h_accumulate(self, h0, xis, alphas):
+    def h_accumulate(self, h0, xis, alphas, out=None):
+        """out: an (n, 4) uint64 array to write into (a caller that keeps its buffer: no fresh pages for the driver to pin)"""
         xis = np.ascontiguousarray(xis, dtype=np.uint64)
         m, lg1 = xis.shape[0], xis.shape[1]
-        out = np.zeros((1 << (lg1 - 1), 4), dtype=np.uint64)
+        if out is None:
+            out = np.empty((1 << (lg1 - 1), 4), dtype=np.uint64)
+        assert out.shape == (1 << (lg1 - 1), 4) and out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
         h0 = None if h0 is None else np.ascontiguousarray(h0, dtype=np.uint64)
         check(self.lib.halo_h_accumulate(self.h, ptr(h0), ptr(xis), ptr(np.ascontiguousarray(alphas, dtype=np.uint64)), m, lg1 - 1, ptr(out)))
         return out

@@ -165,8 +165,15 @@ class ShardedOpen:
         return self.ctx
 
     def _callback(self):
-        cb = self.lib.make_allgather_callback(self.allgather, self.world) if self.allgather is not None else None
-        return cb, (C.cast(cb, C.c_void_p) if cb is not None else None)
+        """-> (object to keep alive, function pointer, user pointer) for halo_pcdl_open_sharded / _check_sharded.  An all-gather
+        that brings its own C entry point (rccl.RcclGather: .fn = halo_allgather_rccl, .user = its handle) is passed as it is --
+        no Python frame in the collective path; anything else is wrapped."""
+        if self.allgather is None:
+            return None, None, None
+        if hasattr(self.allgather, "fn") and hasattr(self.allgather, "user"):
+            return None, self.allgather.fn, self.allgather.user
+        cb = self.lib.make_allgather_callback(self.allgather, self.world)
+        return cb, C.cast(cb, C.c_void_p), None
 
     def open(self, coeffs_local, Cm, z, w=None, rng=None, deg=None):
         """pcdl::open over the sharded key in ONE library call (halo_pcdl_open_sharded): the round loop runs in the library,
@@ -175,9 +182,9 @@ class ShardedOpen:
         deg = p.degree().  -> (proof, v); open_by_rounds is the same protocol spelled out call by call."""
         from ._lib import check, ptr
         if not self.coll:  # one rank, no forced collectives
-            cb, cbp = None, None
+            cb, cbp, user = None, None, None
         else:
-            cb, cbp = self._callback()
+            cb, cbp, user = self._callback()
         co = np.ascontiguousarray(coeffs_local, dtype=np.uint64).reshape(-1, 4)
         lg_n = self.n.bit_length() - 1
         proof = np.zeros(self.lib.load().halo_proof_words(lg_n), dtype=np.uint64)
@@ -185,7 +192,7 @@ class ShardedOpen:
         st = C.c_uint64(rng[0] if rng is not None else 0)
         rc = self.lib.load().halo_pcdl_open_sharded(self.ctx.h, self.world, self.rank, C.byref(st), ptr(co), co.shape[0], int(deg or 0),
                                                     ptr(np.ascontiguousarray(Cm, dtype=np.uint64)), self.n - 1, ptr(np.ascontiguousarray(z, dtype=np.uint64)),
-                                                    ptr(np.ascontiguousarray(w, dtype=np.uint64)) if w is not None else None, cbp, None, ptr(proof), ptr(v))
+                                                    ptr(np.ascontiguousarray(w, dtype=np.uint64)) if w is not None else None, cbp, user, ptr(proof), ptr(v))
         if cb is not None and cb.error is not None:
             raise cb.error
         check(rc)
@@ -199,9 +206,9 @@ class ShardedOpen:
         one all-gather of 96 bytes per rank, the shares added in rank order, U compared (:339).  Raises HaloReject like
         pcdl.check_proof, on every rank alike."""
         from ._lib import check, ptr
-        cb, cbp = self._callback() if self.coll else (None, None)
+        cb, cbp, user = self._callback() if self.coll else (None, None, None)
         a = lambda x: ptr(np.ascontiguousarray(x, dtype=np.uint64))
-        rc = self.lib.load().halo_pcdl_check_sharded(self.ctx.h, self.world, self.rank, a(Cm), d, a(z), a(v), a(proof), cbp, None)
+        rc = self.lib.load().halo_pcdl_check_sharded(self.ctx.h, self.world, self.rank, a(Cm), d, a(z), a(v), a(proof), cbp, user)
         if cb is not None and cb.error is not None:
             raise cb.error
         check(rc)

@@ -65,6 +65,27 @@ def test_development_library_is_separate(hal):
     assert lib.halo_dev_hook(b"no_such_hook", 1) == hal._lib.HALO_E_ARG
 
 
+def test_optional_rccl_library(hal):
+    """include/halo_rccl.h / libhalo_rccl.so: halo_allgather_fn over RCCL for hosts without a collective layer of their own.
+    Optional: the core library neither links nor loads a collective library."""
+    import subprocess
+    from halo_accumulation_amd import rccl
+    core = subprocess.check_output(["ldd", hal._lib.LIB_PATH], text=True)
+    assert "rccl" not in core and "nccl" not in core and "mpi" not in core
+    if not rccl.available():
+        pytest.skip("libhalo_rccl.so not built (no librccl in this image)")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rccl.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (halo_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == header_symbols("halo_rccl.h")
+    assert "librccl" in subprocess.check_output(["ldd", rccl.LIB_PATH], text=True)
+    assert "libhalo_hip" not in subprocess.check_output(["ldd", rccl.LIB_PATH], text=True), "independent of the core library: only the typedef is shared"
+    # the callback type of the core header and the exported function agree (same parameter list)
+    core_h = open(os.path.join(ROOT, "include", "halo_accumulation.h")).read()
+    rccl_h = open(os.path.join(ROOT, "include", "halo_rccl.h")).read()
+    assert "typedef int (*halo_allgather_fn)(void *user, const uint64_t *send, size_t words, uint64_t *recv);" in core_h
+    assert "int halo_allgather_rccl(void *user, const uint64_t *send, size_t words, uint64_t *recv);" in rccl_h
+
+
 def test_public_points_match_consts_rs(hal, kat):
     S, H = hal._lib.public_points()
     hx = lambda p: ["%064x" % p[0], "%064x" % p[1]]

@@ -1033,10 +1033,48 @@ def test_sharded_open_world_one_is_plain_open(hal, ctx):
     so.check(Ch, n - 1, z[0], v, proof)  # world 1: the whole of pcdl::check
 
 
+def test_native_rccl_allgather_world_one(hal, ctx):
+    """libhalo_rccl.so's halo_allgather_rccl -- ncclCommInitRank with ONE rank on this box's GPU -- carries the
+    collectives of halo_pcdl_open_sharded / _check_sharded as a C function pointer (no Python frame in the collective path; the
+    symbol a Rust host links).  Same proof as halo_pcdl_open, hiding and not; the record it gathers is the record it was given."""
+    from halo_accumulation_amd import pcdl, rccl
+    from halo_accumulation_amd.sharded import ShardedOpen
+    if not rccl.available():
+        pytest.skip("libhalo_rccl.so not built (no librccl in this image)")
+    g = rccl.RcclGather(rccl.unique_id(), 0, 1, device=0)
+    try:
+        rec = np.arange(33, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        assert g(rec).tolist() == [rec.tolist()] and g.calls == 1
+        n = 512
+        coeffs, s = orc.rng_scalars(77, n)
+        z, _ = orc.rng_scalars(s, 1)
+        w, _ = orc.rng_scalars(5, 1)
+        so = ShardedOpen(hal._lib, 0, 1, g, always_collective=True)
+        so.load_key(n)
+        C = pcdl.commit(ctx, coeffs, n - 1)
+        before = g.calls
+        proof, v = so.open(coeffs, C, z[0])
+        assert g.calls - before == 1 + 9, "the share of p(z), then one record per round (P = 1: no tail collective)"
+        assert proof.tolist() == pcdl.open(ctx, [1], coeffs, C, n - 1, z[0]).tolist()
+        so.check(C, n - 1, z[0], v, proof)
+        Ch = pcdl.commit(ctx, coeffs, n - 1, w[0])
+        r1, r2 = [77], [77]
+        proof_h, _ = so.open(coeffs, Ch, z[0], w=w[0], rng=r1, deg=n - 1)
+        assert proof_h.tolist() == pcdl.open(ctx, r2, coeffs, Ch, n - 1, z[0], w[0]).tolist() and r1 == r2
+        bad = proof.copy(); bad[2 + 24 * 9 + 3] ^= 1  # U
+        with pytest.raises(ValueError):
+            so.check(C, n - 1, z[0], v, bad)
+        so.ctx.close()
+    finally:
+        g.close()
+
+
 def test_fold_table_automatic_mode_allocates_in_the_background(hal):
-    """Default mode on a context of >= 2^18 points: the first full-size open asks for the table's memory on a helper thread
-    and takes the generic fold; the table is built at the first later open that finds the memory there.  Every open returns
-    the same proof; closing a context while the request is still pending joins the thread and frees what it got."""
+    """Default mode on a context of >= 2^18 points: the table costs 64 opens' worth of savings, so a key earns it
+    by being opened again and again -- the first 7 full-size opens over a key request, reserve and build NOTHING
+    (halo_ctx_info(ctx, 5) == 0, no optional memory on the device's books), the 8th asks for the table's memory on a helper
+    thread and takes the generic fold, and the table is built at the first later open that finds the memory there.  Every
+    open returns the same proof; closing a context while the request is still pending joins the thread and frees what it got."""
     import time
     import torch
     from halo_accumulation_amd import pcdl
@@ -1048,8 +1086,14 @@ def test_fold_table_automatic_mode_allocates_in_the_background(hal):
         c.rng_scalars_dev(0xF01D, n + 1, dv.data_ptr())
         z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
         C = pcdl.commit_dev(c, dv.data_ptr(), n, d)
+        used0 = c.info(4)
         first = pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z)
-        assert c.info(1) == 0, "the first open only asks for the memory"
+        for k in range(2, 8):  # opens 2..7: a caller with a handful of opens never pays for, or reserves memory for, the table
+            assert c.info(5) == 0 and c.info(1) == 0 and c.info(4) == used0, "open %d: nothing requested, nothing reserved" % (k - 1)
+            assert pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z).tolist() == first.tolist()
+        assert c.info(5) == 0 and c.info(1) == 0 and c.info(4) == used0, "seven opens: still nothing"
+        assert pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z).tolist() == first.tolist()  # the 8th asks for the memory
+        assert c.info(5) in (1, 2) and c.info(4) > used0, "the 8th full-size open requests (and reserves) the table's memory"
         built_at = None
         for k in range(40):
             p = pcdl.open_dev(c, [1], dv.data_ptr(), n, C, d, z)
@@ -1071,7 +1115,8 @@ def test_fold_table_automatic_mode_allocates_in_the_background(hal):
         c2.rng_scalars_dev(0xF01D, n + 1, dv.data_ptr())
         z = np.ascontiguousarray(dv[4 * n:].cpu().numpy().view(np.uint64))
         C2 = pcdl.commit_dev(c2, dv.data_ptr(), n, d)
-        assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist()
+        for _ in range(8):  # (the 8th open starts the request)
+            assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist()
         if how == "mode0":
             c2.set_fold_table(0)
             assert pcdl.open_dev(c2, [1], dv.data_ptr(), n, C2, d, z).tolist() == first.tolist() and c2.info(1) == 0

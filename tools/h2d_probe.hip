@@ -61,5 +61,24 @@ int main() {
         double t1 = now(); CK(hipStreamSynchronize(s[0]));
         printf("(f) 4 x 8 MiB on ONE stream: calls return after %.3f ms, done %.3f ms\n", t1 - t0, now() - t0);
     }
+    // (g) the way back: 32 MiB device -> pageable host memory that has been touched / never been touched (a fresh Vec), and through
+    // a pinned staging buffer + memcpy
+    {
+        char *pin; CK(hipHostMalloc(&pin, bytes));
+        for (int rep = 0; rep < 3; ++rep) {
+            double t0 = now(); CK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); double t1 = now();
+            char *fresh = (char *)malloc(bytes);
+            double t2 = now(); CK(hipMemcpy(fresh, d, bytes, hipMemcpyDeviceToHost)); double t3 = now();
+            free(fresh);
+            char *fresh2 = (char *)malloc(bytes);
+            double t4 = now(); CK(hipMemcpy(pin, d, bytes, hipMemcpyDeviceToHost)); double t5 = now(); memcpy(fresh2, pin, bytes); double t6 = now();
+            free(fresh2);
+            char *fresh3 = (char *)calloc(bytes, 1);
+            double t7 = now(); CK(hipMemcpy(fresh3, d, bytes, hipMemcpyDeviceToHost)); double t8 = now();
+            free(fresh3);
+            printf("(g) D2H 32 MiB: into touched pageable %.3f ms; into fresh malloc %.3f ms; pinned staging %.3f + memcpy into fresh malloc %.3f ms; into fresh calloc %.3f ms\n",
+                   t1 - t0, t3 - t2, t5 - t4, t6 - t5, t8 - t7);
+        }
+    }
     return 0;
 }
