@@ -65,7 +65,6 @@ Tuning read_env() {
     t.smsm_waves = env_int("HALO_SMSM_WAVES", t.smsm_waves);
     t.smsm_fused = env_int("HALO_SMSM_FUSED", 0) != 0;
     t.host_inv_fermat = getenv("HALO_HOST_INV_FERMAT") != nullptr;
-    t.late_fused = env_int("HALO_LATE_FUSED", -1);
     t.spin_us = env_int("HALO_SPIN_US", t.spin_us);
     return t;
 }

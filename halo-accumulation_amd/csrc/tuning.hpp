@@ -40,7 +40,6 @@ struct Tuning {
     int smsm_waves = 1024;         // HALO_SMSM_WAVES       wave cap of k_smsm_reduce (0: none)
     bool smsm_fused = false;       // HALO_SMSM_FUSED=1     k_smsm_reduce and k_smsm_final as one launch
     bool host_inv_fermat = false;  // HALO_HOST_INV_FERMAT=1  host inverses by the Fermat power instead of division steps
-    int late_fused = -1;           // HALO_LATE_FUSED=0|1   the small pipeline's kernels behind the sort as one launch (-1: automatic)
     int spin_us = 50;              // HALO_SPIN_US          how long msm_wait polls before it starts yielding the core
 };
 const Tuning &tuning();

@@ -38,13 +38,33 @@ def test_design_quotes_the_committed_kernel_duration_and_the_bench_line():
     assert abs(bench["roofline"]["kernel_ms"] * 1e3 - avg_us) / avg_us < 0.10
     ev = re.search(r"HIP events in the committed `bench.py` run \*\*(\d+) µs\*\*", design)
     assert ev and abs(int(ev.group(1)) - bench["roofline"]["kernel_ms"] * 1e3) < 1.0
-    # headline and open + check as quoted in section 0
-    head = re.search(r"\*\*(\d+) MSM/s\*\* at n = 2\^20", design)
+    # headline and open + check as quoted in section 5
+    head = re.search(r"\*\*(\d+) MSM/s\*\* at n = 2\^20 \((\d+)–(\d+) from box to box", design)
     assert head and abs(int(head.group(1)) - bench["value"]) < 1.0
-    oc = re.search(r"`pcdl::open \+ check` \*\*([\d.]+) ms\*\*", design)
+    oc = re.search(r"`pcdl::open \+ check` \*\*([\d.]+) ms\*\* \(([\d.]+)–([\d.]+) from box to box", design)
     assert oc and abs(float(oc.group(1)) - bench["pcdl_open_check"]["ms"]) < 0.06
     # (the open depends on the host's single-thread speed: the file gives the box-to-box range next to the committed figure)
-    rng = re.search(r"\(([\d.]+)–([\d.]+) from box to box", design)
-    assert rng and float(rng.group(1)) <= bench["pcdl_open_check"]["ms"] + 0.06 and bench["pcdl_open_check"]["ms"] - 0.06 <= float(rng.group(2))
+    assert float(oc.group(2)) <= bench["pcdl_open_check"]["ms"] + 0.06 and bench["pcdl_open_check"]["ms"] - 0.06 <= float(oc.group(3))
     # the roofline fraction is what the definition gives
     assert abs(bench["roofline"]["frac"] - bench["roofline"]["algorithmic_bytes"] / (bench["roofline"]["kernel_ms"] * 1e-3) / 8e12) < 1e-9
+    # VERDICT r4 #7: a "from box to box" range must contain every value the DRIVER has recorded since round 3 (the rounds whose
+    # pipeline the range describes), not only the builder's own runs
+    lo, hi = int(head.group(2)), int(head.group(3))
+    assert lo <= bench["value"] <= hi
+    for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json"))):
+        if int(os.path.basename(f)[7:9]) < 3:
+            continue
+        v = (json.load(open(f)).get("parsed") or {}).get("value")
+        if v is not None:
+            assert lo <= v <= hi, "DESIGN.md's MSM/s range %d-%d does not contain the driver's %s: %.1f" % (lo, hi, os.path.basename(f), v)
+        k = ((json.load(open(f)).get("parsed") or {}).get("roofline") or {}).get("kernel_ms")
+        km = re.search(r"run \*\*\d+ µs\*\* \(([\d.]+)–([\d.]+) from box to box\)", design)
+        assert km, "the bucket kernel's event-timed duration needs its box-to-box range"
+        if k is not None:
+            assert float(km.group(1)) - 0.005 <= k <= float(km.group(2)) + 0.005, (os.path.basename(f), k)
+
+
+def test_design_is_a_spec_not_a_history():
+    """VERDICT r4 #9: the current state in at most 25 KB; what was measured and dropped lives in HISTORY.md."""
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 25 * 1024
+    assert os.path.exists(os.path.join(ROOT, "HISTORY.md"))

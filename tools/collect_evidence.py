@@ -30,6 +30,8 @@ stats("prof_d1_gen", "general_pipeline_depth1_kernel_stats.csv")
 cp(os.path.join(ev, "bench_2_24.json"), "bench_2_24_one_gpu.json")
 cp(os.path.join(ev, "bench_oneproc8_2_24.json"), "rehearsal_oneproc8_2_24_shards_on_1gpu.json")
 cp(os.path.join(ev, "sq_msm.json"), "sq_msm.json")
+cp(os.path.join(ev, "sq_open.json"), "sq_open.json")
+cp(os.path.join(ev, "host_msm.txt"), "host_msm_pageable.txt")
 cp(os.path.join(ev, "pmc_fr.json"), "pmc_open.json")
 cp(os.path.join(ev, "fr_kernels_events.json"), "fr_kernels_events.json")
 cp(os.path.join(ev, "pmc_open_kernels.json"), "pmc_open_loop.json")

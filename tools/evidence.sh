@@ -17,7 +17,7 @@ tail -1 $OUT/pytest_gpu.txt
 step bench;   timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 step prof_d4; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d4 -- python bench.py --steps 40 --warmup 4 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --var-steps 0 --min-seconds 0 > $OUT/prof_d4.log 2>&1 || exit 1
 step prof_d1; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1 -- python bench.py --steps 40 --warmup 4 --depth 1 --cpu-msms 0 --open-steps 0 --asdl-steps 0 --host-steps 0 --fr-reps 0 --var-steps 0 --min-seconds 0 > $OUT/prof_d1.log 2>&1 || exit 1
-step prof_open; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_open -- python tools/open_loop.py 20 5 > $OUT/prof_open.log 2>&1 || exit 1
+step prof_open; FOLD_TABLE=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_open -- python3 tools/open_loop.py 20 5 > $OUT/prof_open.log 2>&1 || exit 1
 python tools/trace_timeline.py $(find $OUT/prof_open -name "*kernel_trace.csv" | head -1) > $OUT/open_timeline.txt 2>&1
 step pmc_fetch; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_fetch.log 2>&1 || exit 1
 step pmc_write; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_write.log 2>&1 || exit 1
@@ -29,7 +29,10 @@ python tools/pmc_summary.py $OUT/pmc_fetch_gen $OUT/pmc_write_gen "TABLE_MODE=0 
 step prof_d1_gen; TABLE_MODE=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d1_gen -- python tools/pipe_loop.py 20 1 40 > $OUT/prof_d1_gen.log 2>&1 || exit 1
 # what the SIMDs do during the integer kernels: issue slots used, clock held, parked wave cycles (tools/sq_summary.py)
 step pmc_sq; timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python tools/pipe_loop.py 20 1 6 > $OUT/pmc_sq.log 2>&1 || exit 1
-python tools/sq_summary.py $OUT/pmc_sq > $OUT/sq_msm.json || exit 1
+python tools/sq_summary.py $OUT/pmc_sq "python tools/pipe_loop.py 20 1 6" "one MSM in flight (n = 2^20)" > $OUT/sq_msm.json || exit 1
+# the same counters over the kernels of an open + check loop (fold table in place from the second open on)
+step pmc_sq_open; FOLD_TABLE=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_open -- python3 tools/open_loop.py 20 4 > $OUT/pmc_sq_open.log 2>&1 || exit 1
+python tools/sq_summary.py $OUT/pmc_sq_open "FOLD_TABLE=1 python3 tools/open_loop.py 20 4" "four pcdl::open + check pairs at n = 2^20, one at a time, fold table requested at the first open" > $OUT/sq_open.json || exit 1
 # the bandwidth-side Fr kernels alone (K4-K9): steady-state durations and HBM-side bytes, each launch back to back
 step fr_trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fr_trace -- python3 tools/fr_kernels.py 20 20 > $OUT/fr_trace.log 2>&1 || exit 1
 step fr_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fr_fetch -- python3 tools/fr_kernels.py 20 6 > $OUT/fr_fetch.log 2>&1 || exit 1
@@ -38,9 +41,11 @@ python tools/pmc_summary.py $OUT/fr_fetch $OUT/fr_write "python3 tools/fr_kernel
 python tools/fr_kernels.py 20 20 > $OUT/fr_kernels_events.json 2>/dev/null || exit 1
 ( cd tools && ./fr29_bench > ../$OUT/fr29_bench.txt 2>&1 ) || true
 # HBM-side bytes of the kernels of an open (the comb-table fold among them)
-step open_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/open_fetch -- python3 tools/open_loop.py 20 4 > $OUT/open_fetch.log 2>&1 || exit 1
-step open_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/open_write -- python3 tools/open_loop.py 20 4 > $OUT/open_write.log 2>&1 || exit 1
-python tools/pmc_summary.py $OUT/open_fetch $OUT/open_write "python3 tools/open_loop.py 20 4" > $OUT/pmc_open_kernels.json || exit 1
+step open_fetch; FOLD_TABLE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/open_fetch -- python3 tools/open_loop.py 20 4 > $OUT/open_fetch.log 2>&1 || exit 1
+step open_write; FOLD_TABLE=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/open_write -- python3 tools/open_loop.py 20 4 > $OUT/open_write.log 2>&1 || exit 1
+python tools/pmc_summary.py $OUT/open_fetch $OUT/open_write "FOLD_TABLE=1 python3 tools/open_loop.py 20 4" > $OUT/pmc_open_kernels.json || exit 1
+# halo_msm from pageable host memory: one copy + one launch sequence against the default stretches (HALO_HOST_SPLIT)
+step host_msm; for cfg in 16 4,12; do HALO_HOST_SPLIT=$cfg timeout -k 10 120 python tools/host_msm.py 20 30 2>/dev/null | grep lg= >> $OUT/host_msm.txt; done
 fi
 if [ "$PART" = A ]; then step done_A; exit 0; fi
 # BASELINE config 5's size on the one GPU: n = 2^24, the bench line (rate with four in flight, solo latency, roofline), and the

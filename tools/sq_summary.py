@@ -2,7 +2,11 @@
 
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU \
               SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d <dir> -- python tools/pipe_loop.py 20 1 6
-    python tools/sq_summary.py <dir> > profiles/rNN_sq_msm.json
+    python tools/sq_summary.py <dir> "python tools/pipe_loop.py 20 1 6" "one MSM in flight (n = 2^20)" > profiles/rNN_sq_msm.json
+
+The profiled program's command line (second argument) is REQUIRED and goes into the file's "command" as given; the third
+argument says what the program had in flight and goes into "note".  (Round 4's r04_sq_open.json carried the MSM loop's command
+and note over the open's kernels: both used to default to the MSM loop here.)
 
 Units as /opt/skills/guides/MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed
 over waves, SQ_INSTS_VALU counts wave-instructions, GRBM_GUI_ACTIVE is the sum over the 8 XCDs of busy shader cycles.
@@ -15,7 +19,10 @@ Derived, per launch (mean over the launches of a kernel in the run):
 """
 import csv, glob, json, os, sys, collections
 
-d = sys.argv[1]
+if len(sys.argv) < 3:
+    sys.exit("usage: sq_summary.py <rocprofv3 output dir> \"<profiled command>\" [\"<what was in flight>\"]")
+d, program = sys.argv[1], sys.argv[2]
+what = sys.argv[3] if len(sys.argv) > 3 else "see command"
 f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
 t = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
 short = lambda s: s.split("(")[0].replace("halo::", "")
@@ -27,8 +34,9 @@ dur = collections.defaultdict(list)
 for r in csv.DictReader(open(t)):
     dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"command": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
-                  "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- " + (sys.argv[2] if len(sys.argv) > 2 else "python tools/pipe_loop.py 20 1 6"),
-       "note": "one MSM in flight (n = 2^20); per launch; durations of the same (counter) pass; 1024 SIMDs", "kernels": {}}
+                  "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- " + program,
+       "note": what + "; per launch; durations of the same (counter) pass; 1024 SIMDs; kernel names are the symbols rocprofv3 prints "
+               "(the event profiler's label k_fold_points4_tab is the symbol k_fold_tab4)", "kernels": {}}
 for k in sorted(tot, key=lambda k: -tot[k].get("SQ_INSTS_VALU", 0) / len(disp[k])):
     n = len(disp[k]); c = {a: b / n for a, b in tot[k].items()}
     us = sum(dur[k]) / len(dur[k]) / 1e3
