@@ -5,12 +5,15 @@ Bit-exactness is defined on canonical affine coordinates (x, y mod p) or the inf
 outputs are compared limb-for-limb where the oracle normalises too.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
 import orc
 import pallas_model as pm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -380,6 +383,45 @@ def test_msm_2_20_vs_oracle(ctx1m):
     got = ctx1m.msm(sc)
     want = orc.msm_affine(gs, sc)  # ~6 s of single-thread CPU
     assert got.tolist() == want.tolist()
+
+
+def test_host_scalar_msm_in_stretches(hal, ctx1m):
+    """halo_msm on scalars in pageable host memory (what integration/ffi.rs point_dot_affine calls) runs a large MSM over the
+    c = 20 table as index stretches on several slots, each behind the copy of its own scalars (abi.hip msm_host_pieces).  Against
+    the oracle, against halo_msm_dev, with adversarial scalars, on a stretch of the key that does not start at 0, and at sizes
+    that do not take the path (not a multiple of 64; below 2^19); other splits in child processes (the split is read once)."""
+    import subprocess, sys, torch
+    n = 1 << 20
+    sc, _ = orc.rng_scalars(0x48414C4F00000002, n)
+    gs = ctx1m.read_bases()
+    ctx1m.msm(sc)  # (the table exists from here on)
+    assert ctx1m.info(0) > 0
+    want = orc.msm_affine(gs, sc)
+    for _ in range(3):  # plain launches, graph capture, replay
+        assert ctx1m.msm(sc).tolist() == want.tolist()
+    d = torch.from_numpy(sc.view(np.int64).copy()).cuda()
+    rm1 = np.tile(np.array(orc.scalars_to_mont([pm.R_ORDER - 1])[0]), (n, 1))
+    half = sc.copy(); half[::2] = 0
+    for name, scal in (("all r-1", rm1), ("half zero", half), ("all zero", np.zeros_like(sc))):
+        dd = torch.from_numpy(np.ascontiguousarray(scal).view(np.int64).copy()).cuda()
+        assert ctx1m.msm(np.ascontiguousarray(scal)).tolist() == ctx1m.msm_dev(dd.data_ptr(), n).tolist(), name
+    # stretches of the key: off != 0, lengths that are / are not multiples of 64, below the threshold
+    for off, m in ((4096, (1 << 19) + 640), (64, (1 << 20) - 64), (12, (1 << 19) + 100), (0, (1 << 19) - 64)):
+        assert ctx1m.msm(np.ascontiguousarray(sc[:m]), off=off).tolist() == ctx1m.msm_dev(d.data_ptr(), m, off=off).tolist(), (off, m)
+    assert ctx1m.msm(sc).tolist() == want.tolist()
+    # a slot busy with the caller's own asynchronous MSM: the synchronous call takes the single-launch form on slot 0 ... which is
+    # busy too -> the library refuses instead of overlapping two launches on one slot
+    ctx1m.msm_dev_begin(0, d.data_ptr(), n)
+    with pytest.raises(hal.HaloError):
+        ctx1m.msm(sc)
+    assert ctx1m.msm_dev_end(0).tolist() == want.tolist()
+    ctx1m.msm_dev_begin(1, d.data_ptr(), n)   # slot 1 busy: one copy + one launch sequence on slot 0
+    assert ctx1m.msm(sc).tolist() == want.tolist()
+    assert ctx1m.msm_dev_end(1).tolist() == want.tolist()
+    for split in ("16", "8,8", "2,3,4,7"):
+        env = dict(os.environ, HALO_HOST_SPLIT=split)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_msm.py"), "20", "3"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and ("HALO_HOST_SPLIT=%s" % split) in out.stdout, out.stderr[-400:]
 
 
 def test_msm_table_pipeline_equals_general(hal):
