@@ -369,7 +369,7 @@ static int succinct_check_batch(halo_ctx *ctx, size_t d, const uint64_t *qs, siz
 // succinct relation; errors are reported in the reference's order (succinct check first).
 static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z, const Fr &v, const uint64_t *proof) {
     SuccinctState st;
-    int rc = succinct_challenges(ctx, C, d, z, v, proof, &st);
+    int rc = succinct_challenges(ctx, C, d, z, v, proof, &st, false);  // (H' = xi_0 H: only the relation needs it -- below, under the MSM)
     if (rc) return rc;
     size_t lg_n = st.lg_n, n = d + 1;
     rc = h_coeffs_dev(ctx, st.xis.data(), lg_n, Fr::one(), false, ctx->d_tmp_a);  // h.get_poly().coeffs
@@ -379,6 +379,7 @@ static int pcdl_check_host(halo_ctx *ctx, const Point &C, size_t d, const Fr &z,
         rc = msm_enqueue(ctx, 0, ctx->d_bases, ctx->d_tmp_a, true, n);  // :338, asynchronous
     }
     if (rc) return rc;
+    st.Hp = public_h_table().mul(st.xis[0]);
     int rc_rel = succinct_relation(st, z, v, proof);
     std::string rel_err = rc_rel ? halo_last_error() : "";
     Point comm;
