@@ -62,11 +62,13 @@ static int ensure_poly_buffers(halo_ctx *ctx) {
     return HALO_OK;
 }
 
-static size_t host_poly_degree(const uint64_t *coeffs, size_t len) {  // DensePolynomial::degree
-    size_t d = 0;
-    for (size_t i = 0; i < len; ++i)
-        if (coeffs[4 * i] | coeffs[4 * i + 1] | coeffs[4 * i + 2] | coeffs[4 * i + 3]) d = i;
-    return d;
+// DensePolynomial::degree: the index of the last non-zero coefficient (0 for the zero polynomial).  Scanned from the END: a
+// dense polynomial answers at its first look (the forward scan this replaces read all 32 MiB of a 2^20-coefficient polynomial
+// on the host, ~1 ms of every halo_pcdl_open / halo_pcdl_commit with host coefficients).
+static size_t host_poly_degree(const uint64_t *coeffs, size_t len) {
+    for (size_t i = len; i-- > 0;)
+        if (coeffs[4 * i] | coeffs[4 * i + 1] | coeffs[4 * i + 2] | coeffs[4 * i + 3]) return i;
+    return 0;
 }
 
 // pedersen::commit over GS[0..n) for device-resident, zero-padded scalars (pedersen.rs:6-20)
