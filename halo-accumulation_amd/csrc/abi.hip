@@ -476,13 +476,14 @@ static int host_pieces_wanted(const halo_ctx *ctx, size_t n) {
         if (ctx->wss[k].in_flight || ctx->wss[k].lent_from >= 0) return 1;
     return P;
 }
-static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uint64_t *scalars, int mont, host::Point *out) {
+// `valid` <= n: the host array holds that many scalars, the MSM's remaining scalars are zero (a polynomial shorter than d + 1)
+static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uint64_t *scalars, size_t valid, int mont, host::Point *out) {
     // stretch k takes host_split[k] sixteenths of the points (n is a multiple of 64: every length a multiple of 4), the last one the rest
     size_t lens[HALO_SLOTS], offs[HALO_SLOTS];
     {
         size_t at = 0;
         for (int k = 0; k < P; ++k) {
-            lens[k] = k == P - 1 ? n - at : n / 64 * (size_t)tuning().host_split[k];
+            lens[k] = k == P - 1 ? n - at : n / 16 * (size_t)tuning().host_split[k];
             offs[k] = at;
             at += lens[k];
         }
@@ -490,12 +491,15 @@ static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uin
     int rc = HALO_OK, started = 0;
     for (int k = 0; k < P && !rc; ++k) {
         const size_t len = lens[k];
+        const size_t have = valid > offs[k] ? (valid - offs[k] < len ? valid - offs[k] : len) : 0;  // scalars of this stretch the caller has
         if (!ctx->d_slot_scalars[k]) {
             alloc_epoch_bump(ctx);
             hipError_t e = hipMalloc(&ctx->d_slot_scalars[k], (ctx->n < 64 ? 64 : ctx->n) * 32);
             if (e != hipSuccess) { rc = hip_fail(e, "hipMalloc"); break; }
         }
-        hipError_t e = hipMemcpyAsync(ctx->d_slot_scalars[k], scalars + 4 * offs[k], len * 32, hipMemcpyHostToDevice, ctx->streams[k]);
+        hipError_t e = hipSuccess;
+        if (have < len) e = hipMemsetAsync(ctx->d_slot_scalars[k] + 4 * have, 0, (len - have) * 32, ctx->streams[k]);
+        if (e == hipSuccess && have) e = hipMemcpyAsync(ctx->d_slot_scalars[k], scalars + 4 * offs[k], have * 32, hipMemcpyHostToDevice, ctx->streams[k]);
         if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync"); break; }
         MsmBatch one;
         one.count = 1;
@@ -514,22 +518,43 @@ static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uin
     *out = acc;
     return rc;
 }
+// One synchronous MSM over GS[off, off + n) with `valid` <= n scalars in pageable host memory (the rest zero): in stretches where
+// that pays (above), else one copy in front of one launch sequence on slot 0.  halo_msm and pcdl::commit / pedersen::commit with host
+// coefficients (pcdl_acc.hip) both end here.
+int halo::msm_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, size_t valid, int mont, host::Point *out) {
+    if (off + n > ctx->n || valid > n || (valid && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
+    const int P = ctx->shards.empty() ? host_pieces_wanted(ctx, n) : 1;
+    if (P > 1) return msm_host_pieces(ctx, P, off, n, scalars, valid, mont, out);
+    if (!ctx->shards.empty() && valid == n) {
+        int rc = multi_begin(ctx, 0, off, n, scalars, nullptr, mont != 0);
+        return rc ? rc : multi_end(ctx, 0, out);
+    }
+    if (ctx->wss[0].in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    if (!ctx->d_slot_scalars[0]) {
+        alloc_epoch_bump(ctx);
+        HALO_HIP(hipMalloc(&ctx->d_slot_scalars[0], (ctx->n < 64 ? 64 : ctx->n) * 32));
+    }
+    if (valid < n) HALO_HIP(hipMemsetAsync(ctx->d_slot_scalars[0] + 4 * valid, 0, (n - valid) * 32, ctx->streams[0]));
+    if (valid) HALO_HIP(hipMemcpyAsync(ctx->d_slot_scalars[0], scalars, valid * 32, hipMemcpyHostToDevice, ctx->streams[0]));
+    if (!ctx->shards.empty()) {  // (a multi-device context with a short polynomial: the padded scalars are device-resident now)
+        HALO_HIP(hipStreamSynchronize(ctx->streams[0]));
+        return msm_run(ctx, ctx->d_bases + 32 * off, ctx->d_slot_scalars[0], mont != 0, n, out);
+    }
+    BorrowScope scope(ctx);  // synchronous: a large MSM may alternate its pieces over slot 1's workspace
+    int rc = msm_enqueue(ctx, 0, ctx->d_bases + 32 * off, ctx->d_slot_scalars[0], mont != 0, n);
+    if (rc) return rc;
+    return msm_finish(ctx, 0, out);
+}
 extern "C" {
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int mont, uint64_t out[12]) {
     if (!out) { set_error("msm: null output"); return HALO_E_ARG; }
     HALO_CTX(ctx);
     if (off + n > ctx->n || (n && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
-    const int P = host_pieces_wanted(ctx, n);
-    if (P > 1) {
-        host::Point r;
-        int rc = msm_host_pieces(ctx, P, off, n, scalars, mont, &r);
-        if (rc) return rc;
-        r.store_normalized(out);
-        return HALO_OK;
-    }
-    int rc = halo_msm_begin(ctx, 0, off, n, scalars, mont);
+    host::Point r;
+    int rc = msm_host_run(ctx, off, n, scalars, n, mont, &r);
     if (rc) return rc;
-    return halo_msm_dev_end(ctx, 0, out);
+    r.store_normalized(out);
+    return HALO_OK;
 }
 
 int halo_msm_points(halo_ctx *ctx, const uint64_t *pts_jac, const uint64_t *scalars, size_t m, uint64_t out[12]) {

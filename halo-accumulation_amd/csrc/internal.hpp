@@ -454,6 +454,7 @@ int multi_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const MsmBa
 int multi_batch_end(halo_ctx *ctx, int slot, host::Point *out, int count);
 int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, bool mont, host::Point *out);
 int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
+int msm_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, size_t valid, int mont, host::Point *out);  // abi.hip: synchronous, host scalars, zero-padded beyond `valid`
 
 // ---- smsm.hip: the 4-launch pipeline for MSMs of up to 2^16 points (digits already in ws.d_canon)
 // (winsum / winsum_plain may be pinned host memory; done: the counter to publish to, or null)

@@ -104,12 +104,14 @@ static int pcdl_commit_host(halo_ctx *ctx, const uint64_t *coeffs, size_t len, s
     if (d + 1 > ctx->n) return fail_assert("commit: d > D");
     size_t used = deg + 1 < len ? deg + 1 : len;
     if (used <= 16) return commit_short_host(ctx, coeffs, used, w, out);
-    int rc = ensure_poly_buffers(ctx);
+    // pedersen::commit over GS[0..n) (pedersen.rs:6-20) with the coefficients still in host memory: halo_msm's path (abi.hip
+    // msm_host_run: the copy in stretches under the kernels where that pays), zero-padded beyond the polynomial
+    Point acc;
+    int rc = msm_host_run(ctx, 0, n, coeffs, used, 1, &acc);
     if (rc) return rc;
-    HALO_HIP(hipMemsetAsync(ctx->d_poly2, 0, n * 32, ctx->stream));
-    rc = upload_words(ctx, ctx->d_poly2, coeffs, used * 4);
-    if (rc) return rc;
-    return pedersen_commit_dev(ctx, w, ctx->d_poly2, n, out);
+    if (w) acc = public_s_table().mul(*w) + acc;
+    *out = acc;
+    return HALO_OK;
 }
 
 // pcdl.rs:120-242 on a device-resident polynomial (d_poly: n coefficients, zero padded, clobbered)
