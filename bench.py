@@ -941,9 +941,21 @@ def main():
         native_gather = None
         from halo_accumulation_amd import rccl as hrccl
         if backend == "nccl" and hrccl.available() and os.environ.get("HALO_BENCH_NATIVE_GATHER", "1") != "0":
-            box = [hrccl.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            native_gather = hrccl.RcclGather(box[0], rank, world, device=gpu)
+            # (optional path: whatever goes wrong here -- on ANY rank -- every rank falls back to the torch.distributed callback;
+            # the agreement itself is a collective, so no rank is left alone with a communicator the others do not have)
+            ok = 1
+            try:
+                box = [hrccl.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                native_gather = hrccl.RcclGather(box[0], rank, world, device=gpu)
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("[bench] native RCCL all-gather not used on rank %d: %s\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and native_gather is not None:
+                native_gather.close()
+                native_gather = None
         so = ShardedOpen(h._lib, rank, world, native_gather if native_gather is not None else ag, device=gpu, always_collective=force_dist)
         sctx = so.load_key(n)
         sctx.set_fold_table(1)  # the comb table of the first fold over this rank's shard, built at the first (warm-up) open

@@ -133,6 +133,7 @@ _SIGS = {
 # when one of these is called -- tests and tools/; the product path (pcdl.py, acc.py, sharded.py, bench.py's timed legs) never does.
 _DEV_SIGS = {
     "halo_dev_hook": (C.c_int, [C.c_char_p, C.c_long]),
+    "halo_dev_tuning": (C.c_long, [C.c_char_p]),
     "halo_set_batch_verify": (C.c_int, [C.c_void_p, C.c_int]),
     "halo_bench_fr_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int]),
     "halo_set_window_bits": (C.c_int, [C.c_void_p, C.c_int]),

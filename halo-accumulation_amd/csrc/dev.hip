@@ -143,6 +143,23 @@ using namespace halo;
 
 extern "C" {
 
+// what tuning() read from the environment (csrc/tuning.hip), by field name: lets a CPU test pin the parsing
+long halo_dev_tuning(const char *name) {
+    if (!name) return -1;
+    const Tuning &t = tuning();
+    if (!std::strcmp(name, "host_pieces")) return t.host_pieces;
+    if (!std::strncmp(name, "host_split", 10) && name[10] >= '0' && name[10] <= '3' && !name[11]) return t.host_split[name[10] - '0'];
+    if (!std::strcmp(name, "fold_table_after")) return t.fold_table_after;
+    if (!std::strcmp(name, "graph_cache")) return t.graph_cache;
+    if (!std::strcmp(name, "pow_e")) return t.pow_e;
+    if (!std::strcmp(name, "spin_us")) return t.spin_us;
+    if (!std::strcmp(name, "graphs")) return t.graphs;
+    if (!std::strcmp(name, "memory_budget")) return t.memory_budget_set ? (long)(t.memory_budget >> 20) : -1;  // MiB
+    if (!std::strcmp(name, "trace")) return t.trace ? 1 : 0;
+    if (!std::strcmp(name, "tagged")) return t.tagged ? 1 : 0;
+    return -1;
+}
+
 int halo_dev_hook(const char *name, long value) {
     if (!name) { set_error("dev_hook: null name"); return HALO_E_ARG; }
     DevHooks &h = dev_hooks();

@@ -25,16 +25,21 @@ Tuning read_env() {
     t.graphs = env_int("HALO_GRAPHS", -1);
     t.fold_async = env_int("HALO_FOLD_ASYNC", -2);
     if (const char *e = getenv("HALO_HOST_SPLIT")) {
+        // "a,b[,c[,d]]": 1 to 4 positive numbers of sixteenths that add up to 16, nothing else in the string
         int v[4] = {0, 0, 0, 0}, k = 0, sum = 0;
-        for (const char *q = e; *q && k < 4; ++k) {
-            v[k] = atoi(q);
-            sum += v[k];
-            const char *comma = strchr(q, ',');
-            if (!comma) { ++k; break; }
-            q = comma + 1;
+        bool ok = true;
+        const char *q = e;
+        while (ok) {
+            char *rest = nullptr;
+            long x = strtol(q, &rest, 10);
+            if (rest == q || x < 1 || x > 16 || k == 4) { ok = false; break; }
+            v[k++] = (int)x;
+            sum += (int)x;
+            if (*rest == 0) break;
+            if (*rest != ',') { ok = false; break; }
+            q = rest + 1;
         }
-        bool ok = k >= 1 && sum == 16;
-        for (int i = 0; i < k; ++i) ok = ok && v[i] >= 1;
+        ok = ok && k >= 1 && sum == 16;
         if (ok) { t.host_pieces = k; for (int i = 0; i < 4; ++i) t.host_split[i] = v[i]; }
         else fprintf(stderr, "[halo] HALO_HOST_SPLIT=%s ignored: 1 to 4 positive numbers of sixteenths that add up to 16\n", e);
     }

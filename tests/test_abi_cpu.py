@@ -65,6 +65,30 @@ def test_development_library_is_separate(hal):
     assert lib.halo_dev_hook(b"no_such_hook", 1) == hal._lib.HALO_E_ARG
 
 
+def test_environment_is_parsed_once_and_strictly(hal):
+    """csrc/tuning.hip: defaults, a valid HALO_HOST_SPLIT, invalid ones (ignored with a line on stderr, the default stays), clamps."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import halo_accumulation_amd as h; l = h.load(); "
+            "print(' '.join(str(l.halo_dev_tuning(n.encode())) for n in sys.argv[1:]))" % ROOT)
+    names = ["host_pieces", "host_split0", "host_split1", "host_split2", "fold_table_after", "graph_cache", "pow_e", "memory_budget", "tagged"]
+
+    def run(env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("HALO_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code] + names, env=e, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-500:]
+        return [int(x) for x in out.stdout.split()], out.stderr
+
+    assert run({})[0] == [2, 4, 12, 0, 8, 8, 0, -1, 1]
+    assert run({"HALO_HOST_SPLIT": "2,6,8", "HALO_FOLD_TABLE_AFTER": "0", "HALO_MEMORY_BUDGET": "3G", "HALO_TAGGED": "0"})[0] == [3, 2, 6, 8, 0, 8, 0, 3072, 0]
+    assert run({"HALO_HOST_SPLIT": "16"})[0][:3] == [1, 16, 0]
+    for bad in ("5,5", "0,16", "4,4,4,4,4", "x", "20"):
+        vals, err = run({"HALO_HOST_SPLIT": bad})
+        assert vals[:3] == [2, 4, 12] and "HALO_HOST_SPLIT" in err, bad
+    vals, err = run({"HALO_GRAPH_CACHE": "99", "HALO_POW_E": "12"})
+    assert vals[5] == 8 and vals[6] == 0 and "HALO_POW_E" in err
+
+
 def test_optional_rccl_library(hal):
     """include/halo_rccl.h / libhalo_rccl.so: halo_allgather_fn over RCCL for hosts without a collective layer of their own.
     Optional: the core library neither links nor loads a collective library."""
