@@ -468,8 +468,20 @@ int halo_msm_end(halo_ctx *ctx, int slot, uint64_t out[12]) { return halo_msm_de
 // the copies of the stretches behind it.  The stretches' points are added on the host in index order.  Same result, bit for
 // bit (points written by the library are normalised).  Not taken: multi-device contexts (each shard copies its own block over
 // its own link already), contexts without the c = 20 table (the first MSM of a context builds it), any slot busy.
+// The stretches of an n-point MSM, in sixteenths: the caller's HALO_HOST_SPLIT at every size, else what was measured best on one
+// box (profiles/r05_host_msm_stretches_sweep.txt): 4 + 12 below 2^21 points (2^20: 1.63 ms against 1.92 for one copy + one launch
+// sequence; a short first stretch lets the kernels start early, and more stretches only serialise behind one another's bucket
+// kernels), 2 + 4 + 4 + 6 from 2^21 points on, where every stretch is a full-size pipeline pass of its own (2^22: 5.2 against 7.7 ms,
+// 2^24: 19.9 against 29.0).
+struct HostSplit { int pieces; int sixteenths[HALO_SLOTS]; };
+static HostSplit host_split_for(size_t n) {
+    const Tuning &t = halo::tuning();
+    if (t.host_split_set) return HostSplit{t.host_pieces, {t.host_split[0], t.host_split[1], t.host_split[2], t.host_split[3]}};
+    if (n >= ((size_t)1 << 21)) return HostSplit{4, {2, 4, 4, 6}};
+    return HostSplit{2, {4, 12, 0, 0}};
+}
 static int host_pieces_wanted(const halo_ctx *ctx, size_t n) {
-    const int P = halo::tuning().host_pieces;  // (= the number of entries of tuning().host_split)
+    const int P = host_split_for(n).pieces;
     if (P < 2 || !ctx->shards.empty() || !ctx->d_table || ctx->tbl.c != 20 || ctx->table_mode == 0 || ctx->window_bits != 0) return 1;
     if (n < ((size_t)1 << 19) || n % 64 != 0) return 1;
     for (int k = 0; k < P; ++k)
@@ -480,10 +492,11 @@ static int host_pieces_wanted(const halo_ctx *ctx, size_t n) {
 static int msm_host_pieces(halo_ctx *ctx, int P, size_t off, size_t n, const uint64_t *scalars, size_t valid, int mont, host::Point *out) {
     // stretch k takes host_split[k] sixteenths of the points (n is a multiple of 64: every length a multiple of 4), the last one the rest
     size_t lens[HALO_SLOTS], offs[HALO_SLOTS];
+    const HostSplit split = host_split_for(n);
     {
         size_t at = 0;
         for (int k = 0; k < P; ++k) {
-            lens[k] = k == P - 1 ? n - at : n / 16 * (size_t)tuning().host_split[k];
+            lens[k] = k == P - 1 ? n - at : n / 16 * (size_t)split.sixteenths[k];
             offs[k] = at;
             at += lens[k];
         }

@@ -147,6 +147,7 @@ extern "C" {
 long halo_dev_tuning(const char *name) {
     if (!name) return -1;
     const Tuning &t = tuning();
+    if (!std::strcmp(name, "host_split_set")) return t.host_split_set ? 1 : 0;
     if (!std::strcmp(name, "host_pieces")) return t.host_pieces;
     if (!std::strncmp(name, "host_split", 10) && name[10] >= '0' && name[10] <= '3' && !name[11]) return t.host_split[name[10] - '0'];
     if (!std::strcmp(name, "fold_table_after")) return t.fold_table_after;

@@ -40,7 +40,7 @@ Tuning read_env() {
             q = rest + 1;
         }
         ok = ok && k >= 1 && sum == 16;
-        if (ok) { t.host_pieces = k; for (int i = 0; i < 4; ++i) t.host_split[i] = v[i]; }
+        if (ok) { t.host_split_set = true; t.host_pieces = k; for (int i = 0; i < 4; ++i) t.host_split[i] = v[i]; }
         else fprintf(stderr, "[halo] HALO_HOST_SPLIT=%s ignored: 1 to 4 positive numbers of sixteenths that add up to 16\n", e);
     }
     t.fold_table_after = env_int("HALO_FOLD_TABLE_AFTER", t.fold_table_after);

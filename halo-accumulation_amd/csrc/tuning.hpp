@@ -18,8 +18,9 @@ struct Tuning {
     size_t memory_budget = 0;      // HALO_MEMORY_BUDGET=48G  optional-memory budget per device for hosts that cannot call halo_set_memory_budget
     int graphs = -1;               // HALO_GRAPHS=0         never replay launch graphs (default: on; halo_set_graphs overrides)
     int fold_async = -2;           // HALO_FOLD_ASYNC=-1|0|1  folds beside the rounds: automatic / never / wherever possible (halo_set_fold_async)
-    int host_pieces = 2;           // HALO_HOST_SPLIT="4,12"  a host-scalar halo_msm runs as stretches of these many sixteenths of its points, each behind
-    int host_split[4] = {4, 12, 0, 0};  //   the copy of its own scalars (at most 4 entries, sum 16; "16": one copy in front of one launch sequence)
+    bool host_split_set = false;   // HALO_HOST_SPLIT="4,12"  a host-scalar halo_msm runs as stretches of these many sixteenths of its points, each behind
+    int host_pieces = 2;           //   the copy of its own scalars (at most 4 entries, sum 16; "16": one copy in front of one launch sequence).  Unset:
+    int host_split[4] = {4, 12, 0, 0};  //   4,12 below 2^21 points, 2,4,4,6 from there on (abi.hip host_split_for: measured, HISTORY.md)
     int fold_table_after = 8;      // HALO_FOLD_TABLE_AFTER=k  automatic mode builds the fold table after k full-size opens on a key (0: never automatically)
     // ---- development switches for A/B runs on one box (tools/ab.sh, tools/env_ab.sh); defaults are the measured winners
     const char *plan = nullptr;    // HALO_PLAN="16:12,15:12"  window bits by lg n for the general / small pipelines

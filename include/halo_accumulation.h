@@ -90,8 +90,8 @@ int halo_public_points(uint64_t S_out[12], uint64_t H_out[12]);
  * scalars_are_mont = 1: arkworks' in-memory Fr (Montgomery limbs); 0: plain little-endian integers below 2^255
  * (canonical Fr values; an unreduced value in [r, 2^255) is taken as it is, which gives the same point).
  * `scalars` is host memory (pageable is fine) and is read only during the call.  Synchronous; over the context's fixed-base table
- * an MSM of >= 2^19 points runs as two index stretches on slots 0 and 1, the second stretch's copy under the first one's kernels
- * (both slots must be idle, else one copy + one launch sequence on slot 0; environment HALO_HOST_SPLIT). */
+ * an MSM of >= 2^19 points runs as two index stretches on slots 0 and 1 (four on slots 0..3 from 2^21 points on), every later
+ * stretch's copy under the earlier ones' kernels (these slots must be idle, else one copy + one launch sequence on slot 0; environment HALO_HOST_SPLIT). */
 int halo_msm(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, int scalars_are_mont, uint64_t out_jac[12]);
 /* Asynchronous halves of halo_msm (scalars in HOST memory): begin() copies the scalars to the device on the slot's own
  * stream and enqueues the launch sequence behind the copy, end() waits and combines.  With two or more slots a caller

@@ -22,7 +22,7 @@ extern "C" {
  * "shard_fail_rank" + "shard_fail_at" (the rank with that offset fails locally before collective number `at` of a sharded open:
  * 0 = the share of p(z), 1.. = the rounds, then the tail; at = -2: in a sharded check), "reset" (all off). */
 int halo_dev_hook(const char *name, long value);
-/* What the library read from the environment at its first use (csrc/tuning.hip), by field: "host_pieces", "host_split0".."host_split3",
+/* What the library read from the environment at its first use (csrc/tuning.hip), by field: "host_split_set", "host_pieces", "host_split0".."host_split3",
  * "fold_table_after", "graph_cache", "pow_e", "spin_us", "graphs", "memory_budget" (MiB, -1 unset), "trace", "tagged"; -1 for an
  * unknown name.  Host only. */
 long halo_dev_tuning(const char *name);

@@ -418,6 +418,19 @@ def test_host_scalar_msm_in_stretches(hal, ctx1m):
     ctx1m.msm_dev_begin(1, d.data_ptr(), n)   # slot 1 busy: one copy + one launch sequence on slot 0
     assert ctx1m.msm(sc).tolist() == want.tolist()
     assert ctx1m.msm_dev_end(1).tolist() == want.tolist()
+    # from 2^21 points on the default is four stretches (2, 4, 4, 6 sixteenths), each of one or more table pieces
+    n2 = 1 << 21
+    big = hal.Context(urs_n=n2)
+    try:
+        d2 = torch.empty(n2 * 4, dtype=torch.int64, device="cuda")
+        big.rng_scalars_dev(0x48414C4F00000005, n2, d2.data_ptr())
+        sc2 = np.ascontiguousarray(d2.cpu().numpy().view(np.uint64).reshape(n2, 4))
+        w2 = big.msm_dev(d2.data_ptr(), n2)          # builds the table
+        for _ in range(3):
+            assert big.msm(sc2).tolist() == w2.tolist()
+        assert big.msm(np.ascontiguousarray(sc2[: n2 - 64]), off=64).tolist() == big.msm_dev(d2.data_ptr(), n2 - 64, off=64).tolist()
+    finally:
+        big.close()
     for split in ("16", "8,8", "2,3,4,7"):
         env = dict(os.environ, HALO_HOST_SPLIT=split)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_msm.py"), "20", "3"], env=env, capture_output=True, text=True, timeout=300)
