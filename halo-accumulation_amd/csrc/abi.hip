@@ -538,10 +538,7 @@ int halo::msm_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scal
     if (off + n > ctx->n || valid > n || (valid && !scalars)) { set_error("msm: bad range or null pointer"); return HALO_E_ARG; }
     const int P = ctx->shards.empty() ? host_pieces_wanted(ctx, n) : 1;
     if (P > 1) return msm_host_pieces(ctx, P, off, n, scalars, valid, mont, out);
-    if (!ctx->shards.empty() && valid == n) {
-        int rc = multi_begin(ctx, 0, off, n, scalars, nullptr, mont != 0);
-        return rc ? rc : multi_end(ctx, 0, out);
-    }
+    if (!ctx->shards.empty() && valid == n) return multi_host_run(ctx, off, n, scalars, mont != 0, out);
     if (ctx->wss[0].in_flight) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
     if (!ctx->d_slot_scalars[0]) {
         alloc_epoch_bump(ctx);

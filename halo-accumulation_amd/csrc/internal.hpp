@@ -453,6 +453,7 @@ int multi_end(halo_ctx *ctx, int slot, host::Point *out);
 int multi_batch_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const MsmBatch &members, bool mont);
 int multi_batch_end(halo_ctx *ctx, int slot, host::Point *out, int count);
 int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, bool mont, host::Point *out);
+int multi_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, bool mont, host::Point *out);  // synchronous, host scalars, per shard msm_host_run
 int msm_host_begin(halo_ctx *ctx, int slot, size_t off, size_t n, const uint64_t *scalars, int mont);  // abi.hip
 int msm_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, size_t valid, int mont, host::Point *out);  // abi.hip: synchronous, host scalars, zero-padded beyond `valid`
 

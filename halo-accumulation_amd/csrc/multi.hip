@@ -244,4 +244,42 @@ int multi_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *dev_scalars, 
     return multi_end(ctx, 0, out);
 }
 
+// The synchronous host-scalar form (halo_msm, pcdl::commit with host coefficients): every shard's helper thread runs its block of
+// GS[off, off + n) through msm_host_run on its own device -- its scalars over its own PCIe link, in stretches where that pays
+// (abi.hip: a shard's block of 2^21 points of an n = 2^24 MSM copies under its own kernels) -- and the partial points are added in
+// block order.  Same point as multi_begin + multi_end give.
+int multi_host_run(halo_ctx *ctx, size_t off, size_t n, const uint64_t *scalars, bool mont, host::Point *out) {
+    if (ctx->fan[0].active) { set_error("msm: slot already has an MSM in flight"); return HALO_E_ARG; }
+    const int P = (int)ctx->shards.size();
+    std::vector<host::Point> part((size_t)P, host::Point::infinity());
+    std::vector<int> rcs((size_t)P, HALO_OK);
+    std::vector<char> used((size_t)P, 0);
+    std::vector<std::string> errs((size_t)P);
+    for (int k = 0; k < P; ++k) {
+        size_t lo = ctx->shard_lo[k], hi = ctx->shard_lo[k + 1];
+        size_t a = std::max(off, lo), b = std::min(off + n, hi);
+        if (a >= b) continue;
+        halo_ctx *s = ctx->shards[k];
+        used[k] = 1;
+        const uint64_t *src = scalars + 4 * (a - off);
+        s->worker.submit([s, a, b, lo, src, mont, &rcs, &errs, &part, k] {
+            (void)hipSetDevice(s->device);
+            rcs[k] = msm_host_run(s, a - lo, b - a, src, b - a, mont ? 1 : 0, &part[k]);
+            if (rcs[k]) errs[k] = halo_last_error();
+        });
+    }
+    int rc = HALO_OK;
+    for (int k = 0; k < P; ++k)
+        if (used[k]) {
+            ctx->shards[k]->worker.wait();
+            if (rcs[k] && !rc) { rc = rcs[k]; set_error(errs[k]); }
+        }
+    (void)hipSetDevice(ctx->device);
+    if (rc) return rc;
+    host::Point acc = host::Point::infinity();
+    for (int k = 0; k < P; ++k) acc = acc + part[k];  // block order
+    *out = acc;
+    return HALO_OK;
+}
+
 }  // namespace halo

@@ -77,6 +77,36 @@ def test_multi_ctx_2_20_equals_single_context(hal, P):
         c.close()
 
 
+def test_multi_ctx_host_scalars_in_stretches_per_shard(hal):
+    """halo_msm on a multi-device context with shard blocks of 2^20 points: every shard's helper thread runs its block through the
+    host-scalar path of a plain context (multi.hip multi_host_run -> abi.hip msm_host_run: its copy in stretches under its own
+    kernels).  Equal to the plain context's point; a stretch of the key that cuts through both blocks; pcdl::commit with host
+    coefficients shorter than d + 1 (zero-padded on the device)."""
+    import torch
+    from halo_accumulation_amd import pcdl
+    n = 1 << 21
+    d = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    one = hal.Context(urs_n=n)
+    try:
+        one.rng_scalars_dev(0x48414C4F00000005, n, d.data_ptr())
+        torch.cuda.synchronize()
+        want = one.msm_dev(d.data_ptr(), n)
+        want_mid = one.msm_dev(d.data_ptr(), n - 8192, off=4096)
+        want_commit = pcdl.commit_dev(one, d.data_ptr(), n - 5, n - 1)
+    finally:
+        one.close()
+    sc = np.ascontiguousarray(d.cpu().numpy().view(np.uint64).reshape(n, 4))
+    c = hal.Context(urs_n=n, devices=[0, 0])
+    try:
+        assert c.msm_dev(d.data_ptr(), n).tolist() == want.tolist()     # (every shard builds its c = 20 table here)
+        for _ in range(3):
+            assert c.msm(sc).tolist() == want.tolist()
+        assert c.msm(np.ascontiguousarray(sc[: n - 8192]), off=4096).tolist() == want_mid.tolist()
+        assert pcdl.commit(c, np.ascontiguousarray(sc[: n - 5]), n - 1).tolist() == want_commit.tolist()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("P,batch", [(2, 2), (4, 4), (8, 8), (3, 5)])
 def test_multi_ctx_batched_launches(hal, P, batch, monkeypatch):
     """halo_msm_dev_batch_begin/_end on a multi-device context: every shard runs its stretch of all members as one batched
