@@ -541,14 +541,12 @@ int halo_pedersen_commit(halo_ctx *ctx, const uint64_t *w, size_t n_bases, const
     HALO_CTX2(ctx);
     if (n_bases != n_ms) return fail_assert("Length did not match for pedersen commitment");  // pedersen.rs:7-12
     if (n_bases > ctx->n) return fail_assert("pedersen commit: more bases than the key holds");
-    int rc = ensure_poly_buffers(ctx);
-    if (rc) return rc;
-    rc = upload_words(ctx, ctx->d_poly2, ms, n_ms * 4);
-    if (rc) return rc;
-    Fr wf = w ? Fr::load(w) : Fr::zero();
+    if (!out || (n_ms && !ms)) { set_error("pedersen commit: null pointer"); return HALO_E_ARG; }
+    // pedersen.rs:14-17 with the scalars in host memory: the host-scalar MSM path of halo_msm (abi.hip msm_host_run)
     Point r;
-    rc = pedersen_commit_dev(ctx, w ? &wf : nullptr, ctx->d_poly2, n_ms, &r);
+    int rc = msm_host_run(ctx, 0, n_ms, ms, n_ms, 1, &r);
     if (rc) return rc;
+    if (w) r = public_s_table().mul(Fr::load(w)) + r;
     r.store_normalized(out);
     return HALO_OK;
 }
