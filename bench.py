@@ -943,14 +943,21 @@ def main():
         if backend == "nccl" and hrccl.available() and os.environ.get("HALO_BENCH_NATIVE_GATHER", "1") != "0":
             # (optional path: whatever goes wrong here -- on ANY rank -- every rank falls back to the torch.distributed callback;
             # the agreement itself is a collective, so no rank is left alone with a communicator the others do not have)
-            ok = 1
-            try:
-                box = [hrccl.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                native_gather = hrccl.RcclGather(box[0], rank, world, device=gpu)
-            except Exception as e:  # noqa: BLE001
-                sys.stderr.write("[bench] native RCCL all-gather not used on rank %d: %s\n" % (rank, e))
+            ok, box = 1, [None]
+            if rank == 0:  # (rank 0 reaches the broadcast whatever happens: the others are waiting in it)
+                try:
+                    box[0] = hrccl.unique_id()
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("[bench] native RCCL all-gather not used: %s\n" % e)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
                 ok = 0
+            else:
+                try:
+                    native_gather = hrccl.RcclGather(box[0], rank, world, device=gpu)
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("[bench] native RCCL all-gather not used on rank %d: %s\n" % (rank, e))
+                    ok = 0
             flag = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0 and native_gather is not None:
