@@ -105,9 +105,16 @@ def _rust_class(param):
     return {"usize": "usize", "c_int": "int", "u64": "u64", "HaloAllgatherFn": "fn"}[ty]
 
 
-def _header_prototypes():
+def _c_class_rccl(param):
+    p = param.strip()
+    if "*" in p or "[" in p:
+        return "ptr"
+    return "usize" if "size_t" in p.split() else "int"
+
+
+def _header_prototypes(name="halo_accumulation.h"):
     import re
-    header = open(os.path.join(ROOT, "include", "halo_accumulation.h")).read()
+    header = open(os.path.join(ROOT, "include", name)).read()
     header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
     protos = {}
     for m in re.finditer(r"\b([A-Za-z_][\w \*]*?)\b(halo_\w+)\s*\(([^;{}]*?)\)\s*;", header):
@@ -184,6 +191,52 @@ def test_ffi_rs_is_structurally_sound():
     for need in ("halo_h_accumulate", "halo_h_eval_batch", "halo_ctx_create_multi"):
         assert need in decls and need in called, need
     assert "HALO_DEVICES" in raw and "dyn PrimeField" not in raw
+
+
+def test_ffi_rccl_rs_matches_its_header():
+    """integration/ffi_rccl.rs (the optional RCCL all-gather for a Rust host) against include/halo_rccl.h: brackets
+    balance, #[link(name = "halo_rccl")] sits on the one extern block, every declaration has the header's arity, parameter
+    classes and return class, and every header symbol is declared."""
+    import re
+    raw = open(os.path.join(ROOT, "integration", "ffi_rccl.rs")).read()
+    src = _strip_rust(raw)
+    pairs, stack = {")": "(", "]": "[", "}": "{"}, []
+    for i, ch in enumerate(src):
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in ")]}":
+            assert stack and stack.pop() == pairs[ch], "unbalanced %r at line %d" % (ch, src.count("\n", 0, i) + 1)
+    assert not stack
+    assert re.search(r'#\[link\s*\(\s*name\s*=\s*"halo_rccl"\s*\)\]\s*extern\s+"C"\s*\{', raw)
+    blocks = list(re.finditer(r'extern\s+"[^"]*"\s*\{', src))
+    assert len(blocks) == 1
+    start = blocks[0].end()
+    depth, i = 1, start
+    while depth:
+        depth += {"{": 1, "}": -1}.get(src[i], 0)
+        i += 1
+    items = [it.strip() for it in src[start:i - 1].split(";")]
+    assert items[-1] == ""
+    protos = _header_prototypes("halo_rccl.h")
+    decls = {}
+    for it in items[:-1]:
+        m = re.fullmatch(r"pub fn (halo_\w+)\s*\((.*)\)\s*(?:->\s*(.+))?", it, flags=re.S)
+        assert m, it[:80]
+        decls[m.group(1)] = (_split_args(m.group(2)), (m.group(3) or "").strip())
+    assert set(decls) == set(protos), (sorted(set(protos) - set(decls)), sorted(set(decls) - set(protos)))
+    for name, (params, ret) in decls.items():
+        c_ret, c_params = protos[name]
+        assert len(params) == len(c_params), name
+        for rp, cp in zip(params, c_params):
+            ty = rp.split(":", 1)[1].strip()
+            got = "ptr" if ty.startswith("*") else {"usize": "usize", "c_int": "int"}[ty]
+            assert got == _c_class_rccl(cp), (name, rp, cp)
+        want = "ptr" if "*" in c_ret else "void" if c_ret.split()[-1] == "void" else "int" if c_ret.split()[-1] == "int" else "usize"
+        got = "ptr" if ret.startswith("*") else "void" if ret == "" else {"c_int": "int", "usize": "usize"}[ret]
+        assert got == want, (name, ret, c_ret)
+    # the callback it hands out has the type the core shim's sharded entry points take
+    assert "crate::ffi::HaloAllgatherFn { Some(halo_allgather_rccl) }" in raw
+    assert "pub type HaloAllgatherFn = Option<unsafe extern \"C\" fn(user: *mut c_void, send: *const u64, words: usize, recv: *mut u64) -> c_int>;" in open(os.path.join(ROOT, "integration", "ffi.rs")).read()
 
 
 def test_shim_declares_only_exported_symbols():
